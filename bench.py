@@ -1,0 +1,156 @@
+#!/usr/bin/env python3
+"""DyCON training-step benchmark on MI355X (contract: see the task description / DESIGN.md section 4).
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+           bench.py --gpus N --steps K --warmup W
+
+One "step" = one full DyCON iteration (teacher noise, student fwd, teacher fwd, CE + Dice + consistency +
+UnCL + FeCL, backward, [RCCL gradient all-reduce], clip + SGD + EMA, weight repack) on one synthetic batch
+that is already resident in HBM.  Workload = BASELINE.json configs[1]: BraTS2019 geometry, V-Net (GroupNorm),
+bf16 activation storage / fp32 accumulate, per-GPU batch 4 (2 labelled + 2 unlabelled), 96^3 patches.
+metric = training volumes / second over all ranks (weak scaling: per-GPU batch fixed).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+MFMA_PEAK_TFLOPS = {"conv_gemm": 2500.0, "conv_wgrad": 157.3}   # dense bf16 MFMA / f32-input MFMA (kernel's arithmetic type)
+
+
+def cpu_baseline(model, patch, seed):
+    """The oracle (plain-PyTorch fp32 CPU restatement of the reference step, oracle/step.py) timed on this
+    box's host cores on a bounded sample: B = 2 (1 labelled + 1 unlabelled), 1 warm-up + 2 timed steps."""
+    from oracle import nets as ON
+    from oracle import step as OS
+    from dycon_paper_replication_amd.synthetic import make_batch
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    mk = ON.make_vnet_params if model == "vnet" else ON.make_unet_params
+    cfg = OS.StepConfig(net_type=model, labeled_bs=1, feature_scaler=2)
+    st = OS.StepState(student=mk(1), teacher=mk(2))
+    vol, lab, noise = make_batch(seed, 2, patch)
+    OS.train_step(cfg, st, vol, lab, noise, 5.0, 0)
+    t0 = time.perf_counter()
+    n = 2
+    for _ in range(n):
+        OS.train_step(cfg, st, vol, lab, noise, 5.0, 0)
+    dt = (time.perf_counter() - t0) / n
+    return {"value": 2.0 / dt, "unit": "volumes/s", "cores": cores, "kind": "port",
+            "sample": f"oracle/step.py (torch {torch.__version__} CPU fp32), {model} B=2 (1+1) at {'x'.join(map(str, patch))}, "
+                      f"1 warm-up + {n} timed steps, {dt:.2f} s/step"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--model", default="vnet", choices=["vnet", "unet_3D"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--batch", type=int, default=4)
+    ap.add_argument("--labeled", type=int, default=2)
+    ap.add_argument("--patch", type=int, nargs=3, default=[96, 96, 96])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch multi-GPU runs with torch.distributed.run (one process per GPU)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    pg = None
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.distributed.init_process_group("nccl", device_id=dev)   # "nccl" == RCCL on ROCm
+        pg = torch.distributed.group.WORLD
+
+    from dycon_paper_replication_amd import ops
+    from dycon_paper_replication_amd.synthetic import make_batch
+    from dycon_paper_replication_amd.trainer import DyconTrainer, TrainConfig
+
+    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    cfg = TrainConfig(model=args.model, batch_size=args.batch, labeled_bs=args.labeled, dtype=dtype, seed=1337)
+    tr = DyconTrainer(cfg, dev, process_group=pg)
+    patch = tuple(args.patch)
+    vol, lab, _ = make_batch(1337 + rank, args.batch, patch)
+    vol, lab = vol.to(dev), lab.to(torch.uint8).to(dev)        # inputs resident in HBM before the timed region
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        tr.step(vol, lab)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = tr.step(vol, lab)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t)
+    ms_per_step = dt / args.steps * 1e3
+    value = args.batch * world * args.steps / dt
+
+    # ---- per-kernel roofline (HIP events on the launch stream, a few extra un-timed steps)
+    roofline = None
+    if not args.no_kernel_timing and rank == 0:
+        ops.PROFILER = ops.KernelProfiler()
+        nprof = 3
+        for _ in range(nprof):
+            tr.step(vol, lab)
+        torch.cuda.synchronize()
+        summ = ops.PROFILER.summary()
+        ops.PROFILER = None
+        dom = max(summ, key=lambda k: summ[k]["ms"])
+        r = summ[dom]
+        sec = r["ms"] * 1e-3
+        gbs = r["bytes"] / sec / 1e9
+        tfl = r["flops"] / sec / 1e12
+        peak_t = MFMA_PEAK_TFLOPS.get(dom, 157.3) if args.dtype == "bf16" else 157.3
+        f_hbm, f_mfma = gbs / HBM_PEAK_GBS, tfl / peak_t
+        bound = "hbm" if (r["bytes"] / (HBM_PEAK_GBS * 1e9)) >= (r["flops"] / (peak_t * 1e12)) else "mfma"
+        roofline = {"kernel": dom, "bound": bound,
+                    "achieved": gbs if bound == "hbm" else tfl, "peak": HBM_PEAK_GBS if bound == "hbm" else peak_t,
+                    "unit": "GB/s" if bound == "hbm" else "TFLOP/s", "frac": f_hbm if bound == "hbm" else f_mfma,
+                    "traffic": None, "avg_launch_ms": r["ms"] / r["launches"], "launches_per_step": r["launches"] // nprof,
+                    "hbm_frac": f_hbm, "mfma_frac": f_mfma,
+                    "per_kernel_ms_per_step": {k: round(v["ms"] / nprof, 4) for k, v in sorted(summ.items(), key=lambda kv: -kv[1]["ms"])}}
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(args.model, patch, 1337)
+
+    if rank == 0:
+        line = {"metric": "train volumes/sec (96^3 patch)", "value": value, "unit": "volumes/s", "n_gpus": world, "steps": args.steps,
+                "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                "dtype": args.dtype, "data": "synthetic",
+                "config": {"workload": f"BraTS2019 labelnum=25 geometry, {args.model} (GroupNorm) {args.dtype}, per-GPU batch "
+                                       f"{args.batch} ({args.labeled} lab + {args.batch - args.labeled} unlab), "
+                                       f"{'x'.join(map(str, patch))} patches, full DyCON step",
+                           "global_batch": args.batch * world, "parallelism": f"dp{world}",
+                           "final_loss": float(out["loss"]), "skipped_steps": tr.skipped_steps},
+                "roofline": roofline, "cpu_baseline": cpu}
+        print(json.dumps(line))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,106 @@
+"""ctypes binding of libdycon_hip.so (the C ABI declared in include/dycon_hip.h).
+
+There is NO fallback: if the shared library is missing or a symbol cannot be resolved this
+module raises, and every op of the package fails loudly.  Build it with
+``python -c "import __graft_entry__ as g; g.build()"`` (or ``make -C dycon_paper_replication_amd/csrc``).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdycon_hip.so")
+
+F32, BF16 = 0, 1
+CONV_1X1, CONV_K3, CONV_K2S2 = 0, 1, 2
+
+P, I, L, F, Z, U64 = C.c_void_p, C.c_int, C.c_longlong, C.c_float, C.c_size_t, C.c_uint64
+
+# name -> (restype, argtypes)        -- must list EVERY function declared in include/dycon_hip.h
+SIGNATURES = {
+    "dycon_version": (I, []),
+    "dycon_last_error": (C.c_char_p, []),
+    "dycon_bfrag_bytes": (Z, [I, I, I, I]),
+    "dycon_pack_bfrag": (I, [P, P, I, I, I, I, I, L, L, L, L, I, P]),
+    "dycon_pack_tcn": (I, [P, P, I, I, I, I, L, L, L, L, I, P]),
+    "dycon_conv_gemm": (I, [P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, P]),
+    "dycon_conv_direct": (I, [P, I, P, P, P, I, I, I, I, I, I, I, I, I, P]),
+    "dycon_conv_wgrad_workspace": (Z, [I, I, I, I, I, I, I]),
+    "dycon_conv_wgrad": (I, [P, I, P, I, P, I, I, I, I, I, I, I, L, L, L, P, Z, P]),
+    "dycon_colsum_workspace": (Z, [L, I]),
+    "dycon_colsum": (I, [P, I, P, L, I, P, Z, P]),
+    "dycon_norm_workspace": (Z, [I, L, I]),
+    "dycon_norm_stats": (I, [P, I, I, L, I, I, F, P, P, P, F, P, Z, P]),
+    "dycon_norm_apply": (I, [P, P, I, I, L, I, I, P, P, P, I, P, P]),
+    "dycon_norm_bwd": (I, [P, I, P, P, I, I, L, I, I, P, P, P, I, P, P, P, Z, P]),
+    "dycon_maxpool2_fwd": (I, [P, P, P, I, I, I, I, I, I, P]),
+    "dycon_maxpool2_bwd": (I, [P, P, P, I, I, I, I, I, I, P]),
+    "dycon_trilinear_fwd": (I, [P, P, I, I, I, I, I, I, I, I, I, I, I, I, P]),
+    "dycon_trilinear_bwd": (I, [P, P, I, I, I, I, I, I, I, I, I, I, I, I, P]),
+    "dycon_copy_channels": (I, [P, I, I, P, I, I, L, I, I, P]),
+    "dycon_scale_channels": (I, [P, P, P, I, I, L, I, P]),
+    "dycon_mul_mask": (I, [P, P, F, P, I, L, P]),
+    "dycon_dropout_philox": (I, [P, P, I, L, F, U64, U64, P]),
+    "dycon_channel_mask_philox": (I, [P, L, F, U64, U64, P]),
+    "dycon_add_noise": (I, [P, P, P, I, L, F, F, U64, U64, P]),
+    "dycon_tanh": (I, [P, I, P, L, P]),
+    "dycon_cast": (I, [P, I, P, I, L, P]),
+    "dycon_add": (I, [P, P, P, I, L, P]),
+    "dycon_seg_losses_fwd": (I, [P, P, P, I, I, I, L, F, P, P]),
+    "dycon_seg_losses_bwd": (I, [P, P, P, I, I, I, L, F, P, P, I, P, P]),
+    "dycon_seg_losses_finalize": (I, [P, I, I, L, F, P, P]),
+    "dycon_step_loss": (I, [P, P, F, F, F, I, I, P, P, P]),
+    "dycon_l2norm_fwd": (I, [P, P, P, I, L, I, F, P]),
+    "dycon_l2norm_bwd": (I, [P, P, P, P, I, L, I, F, P]),
+    "dycon_mask_pool": (I, [P, I, P, I, I, I, I, I, I, I, P]),
+    "dycon_fecl_workspace": (Z, [I, I]),
+    "dycon_fecl_fwd": (I, [P, P, P, P, I, I, I, I, F, F, I, F, F, P, P, P, Z, P]),
+    "dycon_fecl_finalize": (I, [P, C.c_double, F, I, P, P]),
+    "dycon_set_scalars": (I, [P, I, F, F, F, F, F, F, F, F, P]),
+    "dycon_fecl_bwd": (I, [P, P, P, P, I, I, I, I, F, F, I, F, F, P, P, P, P, Z, P]),
+    "dycon_sumsq": (I, [P, L, P, P]),
+    "dycon_sgd_ema": (I, [P, P, P, P, L, L, P, F, F, F, F, F, F, P, P]),
+    "dycon_nonfinite_flag": (I, [P, P, P]),
+}
+
+
+class DyconLibraryError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load():
+    """Load (once) and return the ctypes handle with all prototypes set."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise DyconLibraryError(
+            f"{LIB_PATH} not found: the HIP extension is not built.  Run "
+            "`python -c 'import __graft_entry__ as g; g.build()'` from the repo root.  "
+            "There is no CPU/PyTorch fallback for the DyCON hot path.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:  # pragma: no cover
+            raise DyconLibraryError(f"{LIB_PATH} does not export {name}") from e
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def call(name, *args):
+    """Invoke an int-returning entry point; raise with dycon_last_error() on failure."""
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        raise DyconLibraryError(f"{name} failed ({rc}): {lib.dycon_last_error().decode()}")
+
+
+def query(name, *args):
+    return getattr(load(), name)(*args)

@@ -1,0 +1,666 @@
+// Loss kernels of the DyCON step: the fused voxel losses (CE, Dice, consistency, UnCL), the
+// embedding row-normalisation, the contrastive mask, and the blockwise FeCL.
+#include "common.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// =================================================================================================
+// voxel losses, 2 classes.  logits are (B, V, 2) fp32 (NDHWC with C = 2)
+// =================================================================================================
+__device__ __forceinline__ int load_label(const void* labels, int label_bytes, long long i) {
+    return label_bytes == 8 ? (int)((const long long*)labels)[i] : (int)((const uint8_t*)labels)[i];
+}
+
+struct Soft2 { float p0, p1, lse, m; };
+__device__ __forceinline__ Soft2 softmax2(float l0, float l1) {
+    Soft2 s;
+    s.m = fmaxf(l0, l1);
+    const float e0 = expf(l0 - s.m), e1 = expf(l1 - s.m), z = e0 + e1;
+    s.p0 = e0 / z;
+    s.p1 = e1 / z;
+    s.lse = logf(z);
+    return s;
+}
+
+constexpr int NSUM = 11;
+
+__global__ __launch_bounds__(256) void seg_losses_fwd_kernel(const float2* __restrict__ SL, const float2* __restrict__ TL,
+                                                             const void* __restrict__ labels, int label_bytes, int B, int LB,
+                                                             long long V, float beta, double* __restrict__ sums) {
+    __shared__ float red[4][NSUM];
+    float acc[NSUM];
+#pragma unroll
+    for (int k = 0; k < NSUM; ++k) acc[k] = 0.f;
+    const long long total = (long long)B * V;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int b = (int)(i / V);
+        const float2 ls = SL[i], lt = TL[i];
+        const Soft2 s = softmax2(ls.x, ls.y), t = softmax2(lt.x, lt.y);
+        if (b < LB) {
+            const int y = load_label(labels, label_bytes, i);
+            const float ly = y == 1 ? ls.y : ls.x;
+            acc[0] += -(ly - s.m - s.lse);
+            const float t1 = y == 1 ? 1.f : 0.f, t0 = y == 0 ? 1.f : 0.f;
+            acc[1] += s.p1 * t1; acc[2] += s.p1 * s.p1; acc[3] += t1;
+            acc[4] += s.p0 * t0; acc[5] += s.p0 * s.p0; acc[6] += t0;
+        } else {
+            // the reference feeds PROBABILITIES to softmax_mse_loss / softmax_kl_loss, which softmax again
+            const Soft2 qs = softmax2(s.p0, s.p1), qt = softmax2(t.p0, t.p1);
+            const float d0 = qs.p0 - qt.p0, d1 = qs.p1 - qt.p1;
+            acc[7] += d0 * d0 + d1 * d1;
+            const float lqs0 = s.p0 - qs.m - qs.lse, lqs1 = s.p1 - qs.m - qs.lse;
+            acc[8] += qt.p0 * (logf(qt.p0) - lqs0) + qt.p1 * (logf(qt.p1) - lqs1);
+        }
+        const float hs = -(s.p0 * logf(s.p0 + 1e-6f) + s.p1 * logf(s.p1 + 1e-6f));
+        const float ht = -(t.p0 * logf(t.p0 + 1e-6f) + t.p1 * logf(t.p1 + 1e-6f));
+        const float w = expf(beta * hs) + expf(beta * ht);
+        const float e0 = s.p0 - t.p0, e1 = s.p1 - t.p1;
+        acc[9] += (e0 * e0 + e1 * e1) / w;
+        acc[10] += hs + ht;
+    }
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < NSUM; ++k) {
+        const float v = wave_sum(acc[k]);
+        if (lane == 0) red[wv][k] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < NSUM) {
+        const double v = (double)red[0][threadIdx.x] + (double)red[1][threadIdx.x] + (double)red[2][threadIdx.x] + (double)red[3][threadIdx.x];
+        atomicAdd(&sums[threadIdx.x], v);
+    }
+}
+
+__global__ __launch_bounds__(256) void seg_losses_bwd_kernel(const float2* __restrict__ SL, const float2* __restrict__ TL,
+                                                             const void* __restrict__ labels, int label_bytes, int B, int LB,
+                                                             long long V, float beta, const double* __restrict__ sums,
+                                                             const float* __restrict__ coef, int cons_kind,
+                                                             float2* __restrict__ G) {
+    const float c_ce = coef[0], c_dfg = coef[1], c_dmc = coef[2], c_cons = coef[3], c_uncl = coef[4];
+    const float smooth = 1e-5f;
+    const float I1 = (float)sums[1], D1 = (float)sums[2] + (float)sums[3] + smooth;
+    const float I0 = (float)sums[4], D0 = (float)sums[5] + (float)sums[6] + smooth;
+    const float inv_ce = LB > 0 ? 1.f / ((float)LB * (float)V) : 0.f;
+    const float inv_cons = B > LB ? 1.f / ((float)(B - LB) * (float)V * 2.f) : 0.f;
+    const float inv_all = 1.f / ((float)B * (float)V);
+    const long long total = (long long)B * V;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int b = (int)(i / V);
+        const float2 ls = SL[i], lt = TL[i];
+        const Soft2 s = softmax2(ls.x, ls.y), t = softmax2(lt.x, lt.y);
+        float gp0 = 0.f, gp1 = 0.f;   // d loss / d student probabilities
+        float gl0 = 0.f, gl1 = 0.f;   // direct d loss / d logits (cross entropy)
+        if (b < LB) {
+            const int y = load_label(labels, label_bytes, i);
+            const float t1 = y == 1 ? 1.f : 0.f, t0 = y == 0 ? 1.f : 0.f;
+            gl0 = c_ce * inv_ce * (s.p0 - t0);
+            gl1 = c_ce * inv_ce * (s.p1 - t1);
+            const float dd1 = -(2.f * t1 * D1 - (2.f * I1 + smooth) * 2.f * s.p1) / (D1 * D1);
+            const float dd0 = -(2.f * t0 * D0 - (2.f * I0 + smooth) * 2.f * s.p0) / (D0 * D0);
+            gp1 += c_dfg * dd1 + 0.5f * c_dmc * dd1;
+            gp0 += 0.5f * c_dmc * dd0;
+        } else {
+            const Soft2 qs = softmax2(s.p0, s.p1), qt = softmax2(t.p0, t.p1);
+            float gq0, gq1;   // gradient w.r.t. the inner softmax INPUT (= student probabilities)
+            if (cons_kind == 0) {
+                const float a0 = 2.f * (qs.p0 - qt.p0) * inv_cons, a1 = 2.f * (qs.p1 - qt.p1) * inv_cons;
+                const float dot = qs.p0 * a0 + qs.p1 * a1;
+                gq0 = qs.p0 * (a0 - dot);
+                gq1 = qs.p1 * (a1 - dot);
+            } else {
+                gq0 = (qs.p0 - qt.p0) * inv_cons;
+                gq1 = (qs.p1 - qt.p1) * inv_cons;
+            }
+            gp0 += c_cons * gq0;
+            gp1 += c_cons * gq1;
+        }
+        {
+            const float eps = 1e-6f;
+            const float hs = -(s.p0 * logf(s.p0 + eps) + s.p1 * logf(s.p1 + eps));
+            const float ht = -(t.p0 * logf(t.p0 + eps) + t.p1 * logf(t.p1 + eps));
+            const float ehs = expf(beta * hs), w = ehs + expf(beta * ht);
+            const float e0 = s.p0 - t.p0, e1 = s.p1 - t.p1, d2 = e0 * e0 + e1 * e1;
+            const float dh0 = -(logf(s.p0 + eps) + s.p0 / (s.p0 + eps)), dh1 = -(logf(s.p1 + eps) + s.p1 / (s.p1 + eps));
+            const float k = beta - d2 * beta * ehs / (w * w);
+            gp0 += c_uncl * inv_all * (2.f * e0 / w + dh0 * k);
+            gp1 += c_uncl * inv_all * (2.f * e1 / w + dh1 * k);
+        }
+        const float dot = s.p0 * gp0 + s.p1 * gp1;
+        G[i] = make_float2(gl0 + s.p0 * (gp0 - dot), gl1 + s.p1 * (gp1 - dot));
+    }
+}
+
+// scalars of the voxel losses from the accumulated sums (device-side: no host round trip)
+//   vals: 0 ce | 1 dice (class 1, losses.dice_loss) | 2 dice (mean over classes, losses.DiceLoss) | 3 cons mse | 4 cons kl | 5 uncl
+__global__ void seg_losses_finalize_kernel(const double* __restrict__ sums, int B, int LB, long long V, float beta,
+                                           float* __restrict__ vals) {
+    const double s = 1e-5;
+    const double nl = (double)LB * (double)V, nc = (double)(B - LB) * (double)V * 2.0, na = (double)B * (double)V;
+    const double d1 = 1.0 - (2.0 * sums[1] + s) / (sums[2] + sums[3] + s);
+    const double d0 = 1.0 - (2.0 * sums[4] + s) / (sums[5] + sums[6] + s);
+    vals[0] = LB > 0 ? (float)(sums[0] / nl) : 0.f;
+    vals[1] = (float)d1;
+    vals[2] = (float)(0.5 * (d0 + d1));
+    vals[3] = B > LB ? (float)(sums[7] / nc) : 0.f;
+    vals[4] = B > LB ? (float)(sums[8] / nc) : 0.f;
+    vals[5] = (float)(sums[9] / na + (double)beta * sums[10] / na);
+}
+
+// total = l_w*(ce + dice) + cons_w*cons + u_w*(fecl + uncl)   (train_DyCON_BraTS19.py:355-357) and the NaN/Inf flag (:360-362)
+__global__ void step_loss_kernel(const float* __restrict__ vals, const float* __restrict__ fecl, float l_w, float cons_w,
+                                 float u_w, int dice_kind, int cons_kind, float* __restrict__ out, int* __restrict__ nonfinite) {
+    const float ce = vals[0], dice = vals[dice_kind ? 2 : 1], cons = vals[cons_kind ? 4 : 3], un = vals[5];
+    const float fe = fecl ? fecl[0] : 0.f;
+    const float total = l_w * (ce + dice) + cons_w * cons + u_w * (fe + un);
+    out[0] = total; out[1] = ce; out[2] = dice; out[3] = cons; out[4] = fe; out[5] = un;
+    if (nonfinite) nonfinite[0] = isfinite(total) ? 0 : 1;
+}
+
+// =================================================================================================
+// row L2 normalisation: one wave per row
+// =================================================================================================
+template <typename T>
+__global__ __launch_bounds__(256) void l2norm_fwd_kernel(const T* __restrict__ X, T* __restrict__ Y, float* __restrict__ norms,
+                                                         long long R, int C, float eps) {
+    const int lane = threadIdx.x & 63;
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= R) return;
+    float ss = 0.f;
+    for (int c = lane; c < C; c += 64) { const float v = ldf(X + row * C + c); ss += v * v; }
+    ss = wave_sum(ss);
+    const float nrm = fmaxf(sqrtf(ss), eps);
+    if (lane == 0) norms[row] = nrm;
+    for (int c = lane; c < C; c += 64) stf(Y + row * C + c, ldf(X + row * C + c) / nrm);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void l2norm_bwd_kernel(const T* __restrict__ Y, const float* __restrict__ norms,
+                                                         const T* __restrict__ GY, T* __restrict__ GX, long long R, int C,
+                                                         float eps) {
+    const int lane = threadIdx.x & 63;
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= R) return;
+    float dot = 0.f;
+    for (int c = lane; c < C; c += 64) dot += ldf(Y + row * C + c) * ldf(GY + row * C + c);
+    dot = wave_sum(dot);
+    const float nrm = norms[row];
+    // below the clamp (||x|| < eps) the denominator is the constant eps: no projection term
+    const float proj = nrm > eps ? dot : 0.f;
+    for (int c = lane; c < C; c += 64) stf(GX + row * C + c, (ldf(GY + row * C + c) - ldf(Y + row * C + c) * proj) / nrm);
+}
+
+__global__ void mask_pool_kernel(const void* __restrict__ labels, int label_bytes, float* __restrict__ mask, int B, int D, int H,
+                                 int W, int kd, int kh, int kw) {
+    const int Do = D / kd, Ho = H / kh, Wo = W / kw;
+    const long long total = (long long)B * Do * Ho * Wo;
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    long long q = i;
+    const int x = (int)(q % Wo); q /= Wo;
+    const int y = (int)(q % Ho); q /= Ho;
+    const int z = (int)(q % Do);
+    const int b = (int)(q / Do);
+    float s = 0.f;
+    for (int dz = 0; dz < kd; ++dz)
+        for (int dy = 0; dy < kh; ++dy)
+            for (int dx = 0; dx < kw; ++dx)
+                s += (float)load_label(labels, label_bytes, (((long long)b * D + z * kd + dz) * H + y * kh + dy) * W + x * kw + dx);
+    mask[i] = (s / (float)(kd * kh * kw)) > 0.5f ? 1.f : 0.f;
+}
+
+// =================================================================================================
+// FeCL, blockwise.  One workgroup = 64 rows (patches) of one sample; it walks all 64-column tiles,
+// recomputing the Gram tile S = F_I F_J^T on the matrix cores (f32 MFMA: the epilogue's exp/log
+// chain needs fp32 logits) from LDS-staged rows.  Nothing of size N x N ever reaches HBM.
+//
+// Restated semantics (utils/dycon_losses.py:172-234), per sample:
+//   L_ij = S_ij/tau (i != j), L_ii = 0;  m_j = max_i L_ij (column max; == row max by symmetry);
+//   a_ij = exp(L_ij - m_j);  n_i = sum_{k: class differs} a_ik;  P_ij = a_ij/(a_ij + n_i + 1e-18);
+//   loss_i = u_i * sum_{j same class, j != i} -log(P_ij+1e-18) * w_ij / (cnt_i - 1 + 1e-18),
+//   w_ij = (1-P_ij)^gamma (focal, differentiable) or 1;  cross: -log(1 - f_i.t_j + 1e-18) on
+//   different-class pairs with f_i.t_j > thr, summed over the batch / their count.
+// =================================================================================================
+constexpr int FT = 64;  // tile edge
+
+template <typename T>
+__device__ __forceinline__ void stage_rows(float* __restrict__ dst, int stride, int Dp, const T* __restrict__ src, int row0,
+                                           int N, int Dm) {
+    // dst[r][k] = src[row0 + r][k] (fp32), zero for rows >= N and k >= Dm
+    for (int e = threadIdx.x; e < FT * Dp; e += 256) {
+        const int r = e / Dp, k = e - r * Dp;
+        float v = 0.f;
+        if (row0 + r < N && k < Dm) v = ldf(src + (long long)(row0 + r) * Dm + k);
+        dst[r * stride + k] = v;
+    }
+}
+
+// S tile for this wave: rows 16*wave..+15 of Fi against the 64 rows of Fj.  K order inside a 16-chunk is
+// k = 16q + 4*kg + e so that each lane fetches its 4 consecutive k with one ds_read_b128.
+__device__ __forceinline__ void gram_tile(const float* __restrict__ Fi, const float* __restrict__ Fj, int stride, int nq,
+                                          int wave, int lane, f32x4 acc[4]) {
+    const int r = lane & 15, kg = lane >> 4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float* ap = Fi + (16 * wave + r) * stride + 4 * kg;
+    const float* bp = Fj + r * stride + 4 * kg;
+    for (int q = 0; q < nq; ++q) {
+        const float4 a = *reinterpret_cast<const float4*>(ap + 16 * q);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float4 b = *reinterpret_cast<const float4*>(bp + 16 * j * stride + 16 * q);
+            acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, acc[j], 0, 0, 0);
+            acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, acc[j], 0, 0, 0);
+            acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, acc[j], 0, 0, 0);
+            acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, acc[j], 0, 0, 0);
+        }
+    }
+}
+
+// sum / max over the 16 lanes that share a row group (lane bits 0..3)
+__device__ __forceinline__ float row16_sum(float v) {
+    v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+    return v;
+}
+__device__ __forceinline__ float row16_max(float v) {
+    v = fmaxf(v, __shfl_xor(v, 1, 64)); v = fmaxf(v, __shfl_xor(v, 2, 64));
+    v = fmaxf(v, __shfl_xor(v, 4, 64)); v = fmaxf(v, __shfl_xor(v, 8, 64));
+    return v;
+}
+
+// d/dP of phi(P) = -log(P+eps) * (1-P)^gamma   (gamma = 0 <=> no focal weight)
+__device__ __forceinline__ void focal_terms(float P, float gamma, int focal, float& phi, float& dphi) {
+    const float eps = 1e-18f;
+    const float lg = logf(P + eps);
+    if (!focal) { phi = -lg; dphi = -1.f / (P + eps); return; }
+    const float om = fmaxf(1.f - P, 0.f);
+    const float w = gamma == 2.f ? om * om : powf(om, gamma);
+    const float dw = gamma == 2.f ? 2.f * om : (om > 0.f ? gamma * powf(om, gamma - 1.f) : 0.f);
+    phi = -lg * w;
+    dphi = -w / (P + eps) + dw * lg;
+}
+
+// PASS: 1 row max | 2 negative sums + class counts | 3 loss + H (+ cross sums) | 4 gradient
+template <typename T, int PASS>
+__global__ __launch_bounds__(256) void fecl_kernel(const T* __restrict__ F, const T* __restrict__ Tch,
+                                                   const float* __restrict__ mask, const float* __restrict__ gamb, int N, int Dm,
+                                                   float tau, float gamma, int focal, float thr, float* __restrict__ ws,
+                                                   double* __restrict__ out, const float* __restrict__ coef, float lambda_cross,
+                                                   T* __restrict__ GF, int Btot) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int Dp = (Dm + 15) / 16 * 16, stride = Dp + 4, nq = Dp / 16;
+    float* Fi = lds;
+    float* Fj = lds + FT * stride;
+    float* Tt = Fj + FT * stride;                      // PASS 4 only: 64 x (64+4) weight tile
+    const int tstride = FT + 4;
+    const int b = blockIdx.y, i0 = blockIdx.x * FT;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 15, kg = lane >> 4;
+    const long long BN = (long long)Btot * N;
+    float* wm = ws;            // m_i
+    float* wn = ws + BN;       // n_i
+    float* wc = ws + 2 * BN;   // cnt_i
+    float* wk = ws + 3 * BN;   // kappa_i = u_i / (cnt_i - 1 + 1e-18)
+    float* wh = ws + 4 * BN;   // kappa_i * H_i
+    const T* Fb = F + (long long)b * N * Dm;
+    const T* Tb = Tch ? Tch + (long long)b * N * Dm : nullptr;
+    const float* mb = mask + (long long)b * N;
+    const long long rb = (long long)b * N;
+
+    stage_rows(Fi, stride, Dp, Fb, i0, N, Dm);
+
+    // per-lane row data: rows gi[i] = i0 + 16*wave + 4*kg + i
+    int gi[4];
+    float mrow[4], nrow[4], krow[4], hrow[4], mi[4];
+    bool vi[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        gi[i] = i0 + 16 * wave + 4 * kg + i;
+        vi[i] = gi[i] < N;
+        mrow[i] = vi[i] ? mb[gi[i]] : -1.f;
+        mi[i] = nrow[i] = krow[i] = hrow[i] = 0.f;
+        if (PASS >= 2 && vi[i]) mi[i] = wm[rb + gi[i]];
+        if (PASS >= 3 && vi[i]) nrow[i] = wn[rb + gi[i]];
+        if (PASS >= 4 && vi[i]) { krow[i] = wk[rb + gi[i]]; hrow[i] = wh[rb + gi[i]]; }
+    }
+    float a0[4] = {0.f, 0.f, 0.f, 0.f}, a1[4] = {0.f, 0.f, 0.f, 0.f};   // per-row accumulators of the pass
+    float cnum = 0.f, ccnt = 0.f;
+
+    // PASS 4: persistent output tile  gf[16 rows of this wave][Dp], as Dp/16 accumulators
+    constexpr int MAXNT = 16;   // Dm <= 256
+    f32x4 gacc[MAXNT];
+    if (PASS == 4) {
+#pragma unroll
+        for (int t = 0; t < MAXNT; ++t) gacc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    float cross_scale = 0.f, stud_scale = 0.f;
+    if (PASS == 4) {
+        stud_scale = coef[0] / (float)BN;
+        cross_scale = Tb ? coef[0] * lambda_cross / ((float)out[2] + 1e-18f) : 0.f;
+    }
+
+    for (int j0 = 0; j0 < N; j0 += FT) {
+        __syncthreads();
+        stage_rows(Fj, stride, Dp, Fb, j0, N, Dm);
+        __syncthreads();
+        f32x4 acc[4];
+        gram_tile(Fi, Fj, stride, nq, wave, lane, acc);
+
+        if (PASS == 1) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int gj = j0 + 16 * j + r;
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (gj < N && gj != gi[i]) a0[i] = fmaxf(a0[i], acc[j][i] / tau);
+            }
+        } else if (PASS == 2) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int gj = j0 + 16 * j + r;
+                if (gj >= N) continue;
+                const float mj = wm[rb + gj], mk = mb[gj];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    if (mk == mrow[i]) a1[i] += 1.f;
+                    else a0[i] += expf(acc[j][i] / tau - mj);
+                }
+            }
+        } else if (PASS == 3) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int gj = j0 + 16 * j + r;
+                if (gj >= N) continue;
+                const float mj = wm[rb + gj], mk = mb[gj];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    if (mk == mrow[i]) {
+                        a1[i] += 1.f;
+                        if (gj != gi[i]) {
+                            const float a = expf(acc[j][i] / tau - mj);
+                            const float den = a + nrow[i] + 1e-18f;
+                            const float P = a / den;
+                            float phi, dphi;
+                            focal_terms(P, gamma, focal, phi, dphi);
+                            a0[i] += phi;
+                            hrow[i] += dphi * (-a / (den * den));
+                        }
+                    }
+                }
+            }
+        } else {  // PASS 4: T_ij = dL_ij + dL_ji  -> LDS
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int gj = j0 + 16 * j + r;
+                const bool vj = gj < N;
+                const float mj = vj ? wm[rb + gj] : 0.f, mk = vj ? mb[gj] : -2.f;
+                const float nj = vj ? wn[rb + gj] : 0.f, kj = vj ? wk[rb + gj] : 0.f, hj = vj ? wh[rb + gj] : 0.f;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float tv = 0.f;
+                    if (vj && vi[i] && gj != gi[i]) {
+                        const float l = acc[j][i] / tau;
+                        const float aij = expf(l - mj), aji = expf(l - mi[i]);
+                        if (mk == mrow[i]) {
+                            float phi, dphi;
+                            const float dij = aij + nrow[i] + 1e-18f;
+                            focal_terms(aij / dij, gamma, focal, phi, dphi);
+                            tv = aij * krow[i] * dphi * (nrow[i] + 1e-18f) / (dij * dij);
+                            const float dji = aji + nj + 1e-18f;
+                            focal_terms(aji / dji, gamma, focal, phi, dphi);
+                            tv += aji * kj * dphi * (nj + 1e-18f) / (dji * dji);
+                        } else {
+                            tv = aij * hrow[i] + aji * hj;
+                        }
+                        tv *= stud_scale / tau;
+                    }
+                    Tt[(16 * wave + 4 * kg + i) * tstride + 16 * j + r] = tv;
+                }
+            }
+            __syncthreads();
+            // gf[rows of wave][d] += T[rows][64] * Fj[64][d]
+            for (int s = 0; s < FT / 4; ++s) {
+                const float a = Tt[(16 * wave + r) * tstride + 4 * s + kg];
+                const float* bp = Fj + (4 * s + kg) * stride + r;
+#pragma unroll
+                for (int t = 0; t < MAXNT; ++t)
+                    if (t < nq) gacc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bp[16 * t], gacc[t], 0, 0, 0);
+            }
+        }
+
+        if ((PASS == 3 || PASS == 4) && Tb) {   // cross branch against the teacher rows of this column tile
+            __syncthreads();
+            stage_rows(Fj, stride, Dp, Tb, j0, N, Dm);
+            __syncthreads();
+            gram_tile(Fi, Fj, stride, nq, wave, lane, acc);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int gj = j0 + 16 * j + r;
+                const bool vj = gj < N;
+                const float mk = vj ? mb[gj] : -2.f;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float sx = acc[j][i];
+                    const bool hard = vj && vi[i] && mk != mrow[i] && sx > thr;
+                    if (PASS == 3) {
+                        if (hard) { cnum += -logf(1.f - sx + 1e-18f); ccnt += 1.f; }
+                    } else {
+                        Tt[(16 * wave + 4 * kg + i) * tstride + 16 * j + r] = hard ? cross_scale / (1.f - sx + 1e-18f) : 0.f;
+                    }
+                }
+            }
+            if (PASS == 4) {
+                __syncthreads();
+                for (int s = 0; s < FT / 4; ++s) {
+                    const float a = Tt[(16 * wave + r) * tstride + 4 * s + kg];
+                    const float* bp = Fj + (4 * s + kg) * stride + r;
+#pragma unroll
+                    for (int t = 0; t < MAXNT; ++t)
+                        if (t < nq) gacc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bp[16 * t], gacc[t], 0, 0, 0);
+                }
+            }
+        }
+    }
+
+    // ---- per-pass finish
+    if (PASS == 1) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float v = row16_max(a0[i]);
+            if (r == 0 && vi[i]) wm[rb + gi[i]] = v;
+        }
+    } else if (PASS == 2) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float ns = row16_sum(a0[i]), cs = row16_sum(a1[i]);
+            if (r == 0 && vi[i]) { wn[rb + gi[i]] = ns; wc[rb + gi[i]] = cs; }
+        }
+    } else if (PASS == 3) {
+        float lsum = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float ph = row16_sum(a0[i]), cs = row16_sum(a1[i]), hs = row16_sum(hrow[i]);
+            if (r == 0 && vi[i]) {
+                const float u = gamb ? gamb[rb + gi[i]] : 1.f;
+                const float kap = u / (cs - 1.f + 1e-18f);
+                wk[rb + gi[i]] = kap;
+                wh[rb + gi[i]] = kap * hs;
+                lsum += ph * kap;
+            }
+        }
+        float* red = lds;   // staging buffers are dead; keep ALL LDS in the one dynamic array (16-B aligned base)
+        const float bs = block_sum(lsum, red), bn = block_sum(cnum, red), bc = block_sum(ccnt, red);
+        if (threadIdx.x == 0) {
+            atomicAdd(&out[0], (double)bs);
+            if (Tb) { atomicAdd(&out[1], (double)bn); atomicAdd(&out[2], (double)bc); }
+        }
+    } else {
+        T* gb = GF + (long long)b * N * Dm;
+#pragma unroll
+        for (int t = 0; t < MAXNT; ++t) {
+            if (t >= nq) continue;
+            const int d = 16 * t + r;
+            if (d >= Dm) continue;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (vi[i]) stf(gb + (long long)gi[i] * Dm + d, gacc[t][i]);
+        }
+    }
+}
+
+__global__ void fecl_finalize_kernel(const double* __restrict__ out, double BN, float lambda_cross, int has_teacher,
+                                     float* __restrict__ loss) {
+    double l = out[0] / BN;
+    if (has_teacher) l += (double)lambda_cross * out[1] / (out[2] + 1e-18);
+    loss[0] = (float)l;
+}
+
+// =================================================================================================
+// C ABI
+// =================================================================================================
+static inline int lgrid(long long n) {
+    long long b = (n + 255) / 256;
+    if (b > 2048) b = 2048;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+extern "C" int dycon_seg_losses_fwd(const float* s_logits, const float* t_logits, const void* labels, int label_bytes, int B,
+                                    int LB, long long V, float beta, double* sums, dycon_stream_t stream) {
+    DYCON_REQUIRE(s_logits && t_logits && sums && B > 0 && LB >= 0 && LB <= B && V > 0, "seg_losses_fwd: bad arguments");
+    DYCON_REQUIRE(LB == 0 || labels, "seg_losses_fwd: labels missing");
+    DYCON_REQUIRE(label_bytes == 1 || label_bytes == 8, "seg_losses_fwd: labels must be uint8 or int64");
+    if (hipMemsetAsync(sums, 0, 16 * sizeof(double), stream) != hipSuccess) { dycon_set_error("seg_losses_fwd: memset failed"); return DYCON_ERR_LAUNCH; }
+    seg_losses_fwd_kernel<<<lgrid((long long)B * V), 256, 0, stream>>>((const float2*)s_logits, (const float2*)t_logits, labels,
+                                                                       label_bytes, B, LB, V, beta, sums);
+    DYCON_LAUNCH_CHECK();
+    return DYCON_OK;
+}
+
+extern "C" int dycon_seg_losses_bwd(const float* s_logits, const float* t_logits, const void* labels, int label_bytes, int B,
+                                    int LB, long long V, float beta, const double* sums, const float* coef, int cons_kind,
+                                    float* g_logits, dycon_stream_t stream) {
+    DYCON_REQUIRE(s_logits && t_logits && sums && coef && g_logits && B > 0 && LB >= 0 && LB <= B && V > 0, "seg_losses_bwd: bad arguments");
+    DYCON_REQUIRE(label_bytes == 1 || label_bytes == 8, "seg_losses_bwd: labels must be uint8 or int64");
+    seg_losses_bwd_kernel<<<lgrid((long long)B * V), 256, 0, stream>>>((const float2*)s_logits, (const float2*)t_logits, labels,
+                                                                       label_bytes, B, LB, V, beta, sums, coef, cons_kind,
+                                                                       (float2*)g_logits);
+    DYCON_LAUNCH_CHECK();
+    return DYCON_OK;
+}
+
+extern "C" int dycon_seg_losses_finalize(const double* sums, int B, int LB, long long V, float beta, float* vals,
+                                         dycon_stream_t stream) {
+    DYCON_REQUIRE(sums && vals && B > 0 && LB >= 0 && LB <= B && V > 0, "seg_losses_finalize: bad arguments");
+    seg_losses_finalize_kernel<<<1, 1, 0, stream>>>(sums, B, LB, V, beta, vals);
+    DYCON_LAUNCH_CHECK();
+    return DYCON_OK;
+}
+
+extern "C" int dycon_step_loss(const float* vals, const float* fecl, float l_weight, float cons_weight, float u_weight,
+                               int dice_kind, int cons_kind, float* out, int* nonfinite, dycon_stream_t stream) {
+    DYCON_REQUIRE(vals && out, "step_loss: bad arguments");
+    step_loss_kernel<<<1, 1, 0, stream>>>(vals, fecl, l_weight, cons_weight, u_weight, dice_kind, cons_kind, out, nonfinite);
+    DYCON_LAUNCH_CHECK();
+    return DYCON_OK;
+}
+
+extern "C" int dycon_l2norm_fwd(const void* x, void* y, float* norms, int dtype, long long R, int C, float eps,
+                                dycon_stream_t stream) {
+    DYCON_REQUIRE(x && y && norms && R > 0 && C > 0, "l2norm_fwd: bad arguments");
+    DYCON_DISPATCH(dtype, { l2norm_fwd_kernel<T><<<cdiv(R, 4), 256, 0, stream>>>((const T*)x, (T*)y, norms, R, C, eps); });
+    DYCON_LAUNCH_CHECK();
+    return DYCON_OK;
+}
+
+extern "C" int dycon_l2norm_bwd(const void* y, const float* norms, const void* gy, void* gx, int dtype, long long R, int C,
+                                float eps, dycon_stream_t stream) {
+    DYCON_REQUIRE(y && norms && gy && gx && R > 0 && C > 0, "l2norm_bwd: bad arguments");
+    DYCON_DISPATCH(dtype, { l2norm_bwd_kernel<T><<<cdiv(R, 4), 256, 0, stream>>>((const T*)y, norms, (const T*)gy, (T*)gx, R, C, eps); });
+    DYCON_LAUNCH_CHECK();
+    return DYCON_OK;
+}
+
+extern "C" int dycon_mask_pool(const void* labels, int label_bytes, float* mask, int B, int D, int H, int W, int kd, int kh,
+                               int kw, dycon_stream_t stream) {
+    DYCON_REQUIRE(labels && mask && B > 0 && kd > 0 && kh > 0 && kw > 0 && D >= kd && H >= kh && W >= kw, "mask_pool: bad arguments");
+    DYCON_REQUIRE(label_bytes == 1 || label_bytes == 8, "mask_pool: labels must be uint8 or int64");
+    const long long total = (long long)B * (D / kd) * (H / kh) * (W / kw);
+    mask_pool_kernel<<<cdiv(total, 256), 256, 0, stream>>>(labels, label_bytes, mask, B, D, H, W, kd, kh, kw);
+    DYCON_LAUNCH_CHECK();
+    return DYCON_OK;
+}
+
+extern "C" size_t dycon_fecl_workspace(int B, int N) { return (size_t)5 * B * N * sizeof(float); }
+
+static size_t fecl_lds_bytes(int Dm, bool grad) {
+    const int Dp = (Dm + 15) / 16 * 16, stride = Dp + 4;
+    return ((size_t)2 * FT * stride + (grad ? FT * (FT + 4) : 0)) * sizeof(float);
+}
+
+template <typename T, int PASS>
+static int fecl_launch(const void* feat, const void* teacher, const float* mask, const float* gamb, int B, int N, int Dm,
+                       float tau, float gamma, int focal, float thr, float* ws, double* out, const float* coef, float lambda_cross,
+                       void* gf, dycon_stream_t stream) {
+    const size_t lds = fecl_lds_bytes(Dm, PASS == 4);
+    // > 64 KiB of dynamic LDS needs the opt-in attribute (idempotent, no sync, capture-safe)
+    if (hipFuncSetAttribute((const void*)fecl_kernel<T, PASS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+        dycon_set_error("fecl: cannot reserve %zu bytes of LDS", lds);
+        return DYCON_ERR_LAUNCH;
+    }
+    dim3 grid(cdiv(N, FT), B);
+    fecl_kernel<T, PASS><<<grid, 256, lds, stream>>>((const T*)feat, (const T*)teacher, mask, gamb, N, Dm, tau, gamma, focal, thr, ws,
+                                                    out, coef, lambda_cross, (T*)gf, B);
+    DYCON_LAUNCH_CHECK();
+    return DYCON_OK;
+}
+
+static int fecl_check(const char* who, const void* feat, const float* mask, int B, int N, int Dm, float tau, size_t ws_bytes) {
+    DYCON_REQUIRE(feat && mask && B > 0 && N > 0 && Dm > 0 && tau > 0.f, "%s: bad arguments", who);
+    DYCON_REQUIRE(Dm <= 256, "%s: feature dim %d > 256 not supported", who, Dm);
+    DYCON_REQUIRE(B <= 65535, "%s: batch too large", who);
+    DYCON_REQUIRE(ws_bytes >= dycon_fecl_workspace(B, N), "%s: workspace too small", who);
+    return DYCON_OK;
+}
+
+extern "C" int dycon_fecl_fwd(const void* feat, const void* teacher, const float* mask, const float* gambling, int dtype, int B,
+                              int N, int Dm, float temperature, float gamma, int use_focal, float cross_thresh,
+                              float lambda_cross, double* out, float* loss, float* workspace, size_t ws_bytes,
+                              dycon_stream_t stream) {
+    if (int e = fecl_check("fecl_fwd", feat, mask, B, N, Dm, temperature, ws_bytes)) return e;
+    DYCON_REQUIRE(out && loss && workspace, "fecl_fwd: null pointer");
+    const int focal = use_focal && !gambling;   // the gambling branch overrides the focal result (dycon_losses.py:209-211)
+    if (hipMemsetAsync(out, 0, 4 * sizeof(double), stream) != hipSuccess) { dycon_set_error("fecl_fwd: memset failed"); return DYCON_ERR_LAUNCH; }
+    int e = DYCON_OK;
+    DYCON_DISPATCH(dtype, {
+        e = fecl_launch<T, 1>(feat, nullptr, mask, gambling, B, N, Dm, temperature, gamma, focal, cross_thresh, workspace, out, nullptr, lambda_cross, nullptr, stream);
+        if (!e) e = fecl_launch<T, 2>(feat, nullptr, mask, gambling, B, N, Dm, temperature, gamma, focal, cross_thresh, workspace, out, nullptr, lambda_cross, nullptr, stream);
+        if (!e) e = fecl_launch<T, 3>(feat, teacher, mask, gambling, B, N, Dm, temperature, gamma, focal, cross_thresh, workspace, out, nullptr, lambda_cross, nullptr, stream);
+    });
+    if (e) return e;
+    fecl_finalize_kernel<<<1, 1, 0, stream>>>(out, (double)B * N, lambda_cross, teacher != nullptr, loss);
+    DYCON_LAUNCH_CHECK();
+    return DYCON_OK;
+}
+
+extern "C" int dycon_fecl_finalize(const double* out, double rows, float lambda_cross, int has_teacher, float* loss,
+                                   dycon_stream_t stream) {
+    DYCON_REQUIRE(out && loss && rows > 0, "fecl_finalize: bad arguments");
+    fecl_finalize_kernel<<<1, 1, 0, stream>>>(out, rows, lambda_cross, has_teacher, loss);
+    DYCON_LAUNCH_CHECK();
+    return DYCON_OK;
+}
+
+extern "C" int dycon_fecl_bwd(const void* feat, const void* teacher, const float* mask, const float* gambling, int dtype, int B,
+                              int N, int Dm, float temperature, float gamma, int use_focal, float cross_thresh,
+                              float lambda_cross, const double* out, const float* coef, void* g_feat, float* workspace,
+                              size_t ws_bytes, dycon_stream_t stream) {
+    if (int e = fecl_check("fecl_bwd", feat, mask, B, N, Dm, temperature, ws_bytes)) return e;
+    DYCON_REQUIRE(out && coef && g_feat && workspace, "fecl_bwd: null pointer");
+    const int focal = use_focal && !gambling;
+    int e = DYCON_OK;
+    DYCON_DISPATCH(dtype, {
+        e = fecl_launch<T, 4>(feat, teacher, mask, gambling, B, N, Dm, temperature, gamma, focal, cross_thresh, workspace,
+                              const_cast<double*>(out), coef, lambda_cross, g_feat, stream);
+    });
+    return e;
+}

@@ -1,0 +1,319 @@
+// GroupNorm / InstanceNorm / train-mode BatchNorm on NDHWC activations, one kernel family.
+//
+//   x: (Nb, V, C), G groups of cpg = C/G channels; statistics over V*cpg elements per (n, g).
+//   GroupNorm(16, C)  : VNet.py:20            -> G = 16, affine
+//   InstanceNorm3d(C) : networks/utils.py:105 -> G = C, no affine
+//   BatchNorm3d(C)    : UNet3D_contrastive.py:263,266 (train mode) -> Nb = 1, V = all B*N rows, G = C
+//
+// All passes are pure HBM streams (16-byte loads, channel-fixed per thread so the per-channel
+// partials live in registers); the grid-wide reduction is two-stage and deterministic:
+// per-chunk partials -> tiny finalize kernel (double accumulation).
+#include "common.h"
+
+struct NormPlan { int chunks; long long rows_per_chunk; };
+static NormPlan norm_plan(long long V) {
+    NormPlan p;
+    long long rpc = (V + 511) / 512;
+    if (rpc < 512) rpc = 512;
+    p.rows_per_chunk = rpc;
+    p.chunks = (int)((V + rpc - 1) / rpc);
+    return p;
+}
+
+// ---- stage 1: per-(n, chunk, channel) sums.  MODE 0: {sum x, sum x^2}; MODE 1: {sum g, sum g*xhat}
+template <typename T, int MODE>
+__global__ __launch_bounds__(256) void norm_partial_kernel(const T* __restrict__ S, const T* __restrict__ GY,
+                                                           float* __restrict__ part, long long V, int C, int G,
+                                                           long long rows_per_chunk, const float* __restrict__ stats,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                           int relu, int from_y) {
+    constexpr int VN = Vec16<T>::N;
+    __shared__ float sm[2][256][VN + 1];
+    const int n = blockIdx.y, chunk = blockIdx.x;
+    const int ngrp = C / VN;            // 16-byte groups per row
+    const int rpi = 256 / ngrp;         // rows per iteration (0 if C/VN > 256: rejected on the host)
+    const int cg = threadIdx.x % ngrp, rr = threadIdx.x / ngrp;
+    const long long v0 = chunk * rows_per_chunk, v1 = min(V, v0 + rows_per_chunk);
+    const int cpg = C / G;
+    float a0[VN], a1[VN];
+#pragma unroll
+    for (int k = 0; k < VN; ++k) a0[k] = a1[k] = 0.f;
+    float mean[VN], rstd[VN], gm[VN], bt[VN];
+    if (MODE == 1) {
+#pragma unroll
+        for (int k = 0; k < VN; ++k) {
+            const int c = cg * VN + k;
+            const int g = c / cpg;
+            mean[k] = stats[((long long)n * G + g) * 2];
+            rstd[k] = stats[((long long)n * G + g) * 2 + 1];
+            gm[k] = gamma ? gamma[c] : 1.f;
+            bt[k] = beta ? beta[c] : 0.f;
+        }
+    }
+    if (rr < rpi) {
+        const T* sp = S + ((long long)n * V) * C + cg * VN;
+        const T* gp = MODE == 1 ? GY + ((long long)n * V) * C + cg * VN : nullptr;
+        for (long long v = v0 + rr; v < v1; v += rpi) {
+            const Vec16<T> s = ld16(sp + v * C);
+            if (MODE == 0) {
+#pragma unroll
+                for (int k = 0; k < VN; ++k) {
+                    const float x = s.get(k);
+                    a0[k] += x;
+                    a1[k] += x * x;
+                }
+            } else {
+                const Vec16<T> gv = ld16(gp + v * C);
+#pragma unroll
+                for (int k = 0; k < VN; ++k) {
+                    float xh, g = gv.get(k);
+                    if (from_y) {
+                        const float y = s.get(k);
+                        xh = (y - bt[k]) / gm[k];
+                        if (relu && !(y > 0.f)) g = 0.f;
+                    } else {
+                        xh = (s.get(k) - mean[k]) * rstd[k];
+                        if (relu && !(gm[k] * xh + bt[k] > 0.f)) g = 0.f;
+                    }
+                    a0[k] += g;
+                    a1[k] += g * xh;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < VN; ++k) { sm[0][threadIdx.x][k] = a0[k]; sm[1][threadIdx.x][k] = a1[k]; }
+    __syncthreads();
+    // thread (cg, k) pairs: C outputs x 2
+    for (int o = threadIdx.x; o < C; o += 256) {
+        const int og = o / VN, ok = o % VN;
+        float s0 = 0.f, s1 = 0.f;
+        for (int q = 0; q < rpi; ++q) { s0 += sm[0][q * ngrp + og][ok]; s1 += sm[1][q * ngrp + og][ok]; }
+        float* d = part + ((((long long)n * gridDim.x + chunk) * C) + o) * 2;
+        d[0] = s0;
+        d[1] = s1;
+    }
+}
+
+// ---- stage 2 (forward): mean / rstd per (n, g) (+ BatchNorm running statistics)
+__global__ void norm_finalize_stats_kernel(const float* __restrict__ part, int Nb, int chunks, int C, int G, long long V,
+                                           float eps, float* __restrict__ stats, float* running_mean, float* running_var,
+                                           float momentum) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= Nb * G) return;
+    const int n = i / G, g = i % G, cpg = C / G;
+    double s0 = 0.0, s1 = 0.0;
+    for (int ch = 0; ch < chunks; ++ch)
+        for (int c = g * cpg; c < (g + 1) * cpg; ++c) {
+            const float* p = part + ((((long long)n * chunks + ch) * C) + c) * 2;
+            s0 += p[0];
+            s1 += p[1];
+        }
+    const double cnt = (double)V * cpg;
+    const double mean = s0 / cnt;
+    double var = s1 / cnt - mean * mean;
+    if (var < 0.0) var = 0.0;
+    stats[(long long)i * 2] = (float)mean;
+    stats[(long long)i * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+    if (running_mean && Nb == 1 && G == C) {   // nn.BatchNorm3d: unbiased variance in the running estimate
+        running_mean[g] = (1.f - momentum) * running_mean[g] + momentum * (float)mean;
+        const double unb = cnt > 1.0 ? var * cnt / (cnt - 1.0) : var;
+        running_var[g] = (1.f - momentum) * running_var[g] + momentum * (float)unb;
+    }
+}
+
+// ---- stage 2 (backward): per-(n,g) {A, B} and per-channel dgamma/dbeta
+__global__ void norm_finalize_bwd_kernel(const float* __restrict__ part, int Nb, int chunks, int C, int G,
+                                         const float* __restrict__ gamma, float* __restrict__ ab, float* dgamma,
+                                         float* dbeta) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int cpg = C / G;
+    if (i < Nb * G) {
+        const int n = i / G, g = i % G;
+        double A = 0.0, Bq = 0.0;
+        for (int c = g * cpg; c < (g + 1) * cpg; ++c) {
+            double s0 = 0.0, s1 = 0.0;
+            for (int ch = 0; ch < chunks; ++ch) {
+                const float* p = part + ((((long long)n * chunks + ch) * C) + c) * 2;
+                s0 += p[0];
+                s1 += p[1];
+            }
+            const double gm = gamma ? (double)gamma[c] : 1.0;
+            A += gm * s0;
+            Bq += gm * s1;
+        }
+        ab[(long long)i * 2] = (float)A;
+        ab[(long long)i * 2 + 1] = (float)Bq;
+    }
+    if (i < C && (dgamma || dbeta)) {
+        double s0 = 0.0, s1 = 0.0;
+        for (int n = 0; n < Nb; ++n)
+            for (int ch = 0; ch < chunks; ++ch) {
+                const float* p = part + ((((long long)n * chunks + ch) * C) + i) * 2;
+                s0 += p[0];
+                s1 += p[1];
+            }
+        if (dbeta) dbeta[i] = (float)s0;
+        if (dgamma) dgamma[i] = (float)s1;
+    }
+}
+
+// ---- apply: y = act(x*scale[c] + shift[c]) + skip      (per sample n = blockIdx.y)
+template <typename T>
+__global__ __launch_bounds__(256) void norm_apply_kernel(const T* __restrict__ X, T* __restrict__ Y, long long V, int C, int G,
+                                                         const float* __restrict__ stats, const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, int relu, const T* __restrict__ skip) {
+    constexpr int VN = Vec16<T>::N;
+    extern __shared__ float ss[];  // scale[C], shift[C]
+    const int n = blockIdx.y, cpg = C / G;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        const int g = c / cpg;
+        const float mean = stats[((long long)n * G + g) * 2], rstd = stats[((long long)n * G + g) * 2 + 1];
+        const float gm = gamma ? gamma[c] : 1.f, bt = beta ? beta[c] : 0.f;
+        ss[c] = rstd * gm;
+        ss[C + c] = bt - mean * rstd * gm;
+    }
+    __syncthreads();
+    const long long total = V * C / VN;
+    const long long base = (long long)n * V * C;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long e = i * VN;
+        const int c0 = (int)(e % C);
+        Vec16<T> x = ld16(X + base + e), s;
+        if (skip) s = ld16(skip + base + e);
+        Vec16<T> y;
+#pragma unroll
+        for (int k = 0; k < VN; ++k) {
+            float v = x.get(k) * ss[c0 + k] + ss[C + c0 + k];
+            if (relu) v = fmaxf(v, 0.f);
+            if (skip) v += s.get(k);
+            y.set(k, v);
+        }
+        st16(Y + base + e, y);
+    }
+}
+
+// ---- backward apply: gx = rstd * (gamma*g - (A + xhat*B)/cnt)
+template <typename T>
+__global__ __launch_bounds__(256) void norm_bwd_apply_kernel(const T* __restrict__ S, const T* __restrict__ GY, T* __restrict__ GX,
+                                                             long long V, int C, int G, const float* __restrict__ stats,
+                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                             const float* __restrict__ ab, int relu, int from_y) {
+    constexpr int VN = Vec16<T>::N;
+    extern __shared__ float ss[];  // per channel: mean, rstd, gamma, beta, A/cnt, B/cnt
+    const int n = blockIdx.y, cpg = C / G;
+    const float inv_cnt = 1.f / ((float)V * (float)cpg);
+    for (int c = threadIdx.x; c < C; c += 256) {
+        const int g = c / cpg;
+        ss[c] = stats[((long long)n * G + g) * 2];
+        ss[C + c] = stats[((long long)n * G + g) * 2 + 1];
+        ss[2 * C + c] = gamma ? gamma[c] : 1.f;
+        ss[3 * C + c] = beta ? beta[c] : 0.f;
+        ss[4 * C + c] = ab[((long long)n * G + g) * 2] * inv_cnt;
+        ss[5 * C + c] = ab[((long long)n * G + g) * 2 + 1] * inv_cnt;
+    }
+    __syncthreads();
+    const long long total = V * C / VN;
+    const long long base = (long long)n * V * C;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long e = i * VN;
+        const int c0 = (int)(e % C);
+        const Vec16<T> s = ld16(S + base + e), gv = ld16(GY + base + e);
+        Vec16<T> o;
+#pragma unroll
+        for (int k = 0; k < VN; ++k) {
+            const int c = c0 + k;
+            const float gm = ss[2 * C + c], bt = ss[3 * C + c], rstd = ss[C + c];
+            float xh, g = gv.get(k);
+            if (from_y) {
+                const float y = s.get(k);
+                xh = (y - bt) / gm;
+                if (relu && !(y > 0.f)) g = 0.f;
+            } else {
+                xh = (s.get(k) - ss[c]) * rstd;
+                if (relu && !(gm * xh + bt > 0.f)) g = 0.f;
+            }
+            o.set(k, rstd * (gm * g - (ss[4 * C + c] + xh * ss[5 * C + c])));
+        }
+        st16(GX + base + e, o);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+extern "C" size_t dycon_norm_workspace(int Nb, long long V, int C) {
+    const NormPlan p = norm_plan(V);
+    return ((size_t)Nb * p.chunks * C * 2 + (size_t)Nb * C * 2 + 64) * sizeof(float);
+}
+
+static int norm_check(const char* who, int dtype, int Nb, long long V, int C, int G) {
+    const int VN = dtype == DYCON_BF16 ? 8 : 4;
+    DYCON_REQUIRE(Nb > 0 && V > 0 && C > 0 && G > 0 && C % G == 0, "%s: bad shape Nb=%d V=%lld C=%d G=%d", who, Nb, V, C, G);
+    DYCON_REQUIRE(C % VN == 0 && C / VN <= 256, "%s: C=%d must be a multiple of %d and <= %d", who, C, VN, 256 * VN);
+    DYCON_REQUIRE(Nb <= 65535, "%s: Nb too large", who);
+    return DYCON_OK;
+}
+
+extern "C" int dycon_norm_stats(const void* x, int dtype, int Nb, long long V, int C, int G, float eps, float* stats,
+                                float* running_mean, float* running_var, float momentum, float* workspace, size_t ws_bytes,
+                                dycon_stream_t stream) {
+    DYCON_REQUIRE(x && stats && workspace, "norm_stats: null pointer");
+    if (int e = norm_check("norm_stats", dtype, Nb, V, C, G)) return e;
+    DYCON_REQUIRE(ws_bytes >= dycon_norm_workspace(Nb, V, C), "norm_stats: workspace too small");
+    const NormPlan p = norm_plan(V);
+    dim3 grid(p.chunks, Nb);
+    DYCON_DISPATCH(dtype, {
+        norm_partial_kernel<T, 0><<<grid, 256, 0, stream>>>((const T*)x, nullptr, workspace, V, C, G, p.rows_per_chunk, nullptr,
+                                                            nullptr, nullptr, 0, 0);
+    });
+    DYCON_LAUNCH_CHECK();
+    norm_finalize_stats_kernel<<<cdiv((long long)Nb * G, 128), 128, 0, stream>>>(workspace, Nb, p.chunks, C, G, V, eps, stats,
+                                                                                 running_mean, running_var, momentum);
+    DYCON_LAUNCH_CHECK();
+    return DYCON_OK;
+}
+
+static int apply_grid(long long V, int C, int VN) {
+    long long blocks = (V * C / VN + 256 * 4 - 1) / (256 * 4);
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    return (int)blocks;
+}
+
+extern "C" int dycon_norm_apply(const void* x, void* y, int dtype, int Nb, long long V, int C, int G, const float* stats,
+                                const float* gamma, const float* beta, int relu, const void* skip, dycon_stream_t stream) {
+    DYCON_REQUIRE(x && y && stats, "norm_apply: null pointer");
+    if (int e = norm_check("norm_apply", dtype, Nb, V, C, G)) return e;
+    DYCON_DISPATCH(dtype, {
+        dim3 grid(apply_grid(V, C, Vec16<T>::N), Nb);
+        norm_apply_kernel<T><<<grid, 256, 2 * C * sizeof(float), stream>>>((const T*)x, (T*)y, V, C, G, stats, gamma, beta, relu,
+                                                                           (const T*)skip);
+    });
+    DYCON_LAUNCH_CHECK();
+    return DYCON_OK;
+}
+
+extern "C" int dycon_norm_bwd(const void* src, int from_y, const void* gy, void* gx, int dtype, int Nb, long long V, int C,
+                              int G, const float* stats, const float* gamma, const float* beta, int relu, float* dgamma,
+                              float* dbeta, float* workspace, size_t ws_bytes, dycon_stream_t stream) {
+    DYCON_REQUIRE(src && gy && gx && stats && workspace, "norm_bwd: null pointer");
+    if (int e = norm_check("norm_bwd", dtype, Nb, V, C, G)) return e;
+    DYCON_REQUIRE(ws_bytes >= dycon_norm_workspace(Nb, V, C), "norm_bwd: workspace too small");
+    const NormPlan p = norm_plan(V);
+    float* ab = workspace + (size_t)Nb * p.chunks * C * 2;
+    dim3 grid(p.chunks, Nb);
+    DYCON_DISPATCH(dtype, {
+        norm_partial_kernel<T, 1><<<grid, 256, 0, stream>>>((const T*)src, (const T*)gy, workspace, V, C, G, p.rows_per_chunk,
+                                                            stats, gamma, beta, relu, from_y);
+    });
+    DYCON_LAUNCH_CHECK();
+    const int nfin = (Nb * G > C ? Nb * G : C);
+    norm_finalize_bwd_kernel<<<cdiv(nfin, 128), 128, 0, stream>>>(workspace, Nb, p.chunks, C, G, gamma, ab, dgamma, dbeta);
+    DYCON_LAUNCH_CHECK();
+    DYCON_DISPATCH(dtype, {
+        dim3 grid2(apply_grid(V, C, Vec16<T>::N), Nb);
+        norm_bwd_apply_kernel<T><<<grid2, 256, 6 * C * sizeof(float), stream>>>((const T*)src, (const T*)gy, (T*)gx, V, C, G, stats,
+                                                                                gamma, beta, ab, relu, from_y);
+    });
+    DYCON_LAUNCH_CHECK();
+    return DYCON_OK;
+}

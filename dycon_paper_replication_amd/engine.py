@@ -1,0 +1,427 @@
+"""Explicit forward/backward executor for the two DyCON segmentation nets on the HIP kernels.
+
+The reference builds its nets from torch.nn modules and lets autograd walk them
+(code/networks/VNet.py:145-239, code/networks/UNet3D_contrastive.py:207-316).  Here the topology is
+a fixed launch sequence over libdycon_hip.so: the forward pushes one backward closure per op on a
+tape, the backward replays the tape in reverse.  No torch math, no autograd graph, no host sync:
+one step is a pure stream of kernel launches and can be captured into a hipGraph.
+
+Activations are NDHWC tensors (B, D, H, W, C) in ``dtype`` (fp32 parity mode or bf16); logits are
+always fp32.  Parameters stay in the reference's torch layouts/names (state_dict contract).
+"""
+from __future__ import annotations
+
+from collections import OrderedDict
+from typing import Dict, Optional
+
+import torch
+
+from . import ops
+from ._lib import CONV_1X1, CONV_K2S2, CONV_K3
+
+UNET_FILTERS = (16, 32, 64, 128, 256)
+
+
+# --------------------------------------------------------------------------------------
+# parameter specifications (names / shapes / order == the reference modules' state_dict)
+# --------------------------------------------------------------------------------------
+def _projection_spec(spec, c_in):
+    spec["projection.0.weight"] = (512, c_in, 1, 1, 1)
+    spec["projection.0.bias"] = (512,)
+    spec["projection.1.weight"] = (512,)
+    spec["projection.1.bias"] = (512,)
+    spec["projection.3.weight"] = (256, 512, 1, 1, 1)
+    spec["projection.3.bias"] = (256,)
+    spec["projection.4.weight"] = (256,)
+    spec["projection.4.bias"] = (256,)
+
+
+def projection_buffers():
+    return OrderedDict([("projection.1.running_mean", (512,)), ("projection.1.running_var", (512,)),
+                        ("projection.1.num_batches_tracked", ()), ("projection.4.running_mean", (256,)),
+                        ("projection.4.running_var", (256,)), ("projection.4.num_batches_tracked", ())])
+
+
+def vnet_param_spec(in_ch=1, n_classes=2, normalization="groupnorm", nf=16):
+    """VNet.__init__ registration order (VNet.py:150-175) + the DyCON projection head."""
+    spec = OrderedDict()
+    affine = normalization == "groupnorm"
+    step = 3
+
+    def block(name, n, cin, cout):
+        for i in range(n):
+            ci = cin if i == 0 else cout
+            spec[f"{name}.conv.{step * i}.weight"] = (cout, ci, 3, 3, 3)
+            spec[f"{name}.conv.{step * i}.bias"] = (cout,)
+            if affine:
+                spec[f"{name}.conv.{step * i + 1}.weight"] = (cout,)
+                spec[f"{name}.conv.{step * i + 1}.bias"] = (cout,)
+
+    def down(name, cin, cout):
+        spec[f"{name}.conv.0.weight"] = (cout, cin, 2, 2, 2)
+        spec[f"{name}.conv.0.bias"] = (cout,)
+        if affine:
+            spec[f"{name}.conv.1.weight"] = (cout,)
+            spec[f"{name}.conv.1.bias"] = (cout,)
+
+    def up(name, cin, cout):
+        spec[f"{name}.conv.0.weight"] = (cin, cout, 2, 2, 2)
+        spec[f"{name}.conv.0.bias"] = (cout,)
+        if affine:
+            spec[f"{name}.conv.1.weight"] = (cout,)
+            spec[f"{name}.conv.1.bias"] = (cout,)
+
+    block("block_one", 1, in_ch, nf); down("block_one_dw", nf, 2 * nf)
+    block("block_two", 2, 2 * nf, 2 * nf); down("block_two_dw", 2 * nf, 4 * nf)
+    block("block_three", 3, 4 * nf, 4 * nf); down("block_three_dw", 4 * nf, 8 * nf)
+    block("block_four", 3, 8 * nf, 8 * nf); down("block_four_dw", 8 * nf, 16 * nf)
+    block("block_five", 3, 16 * nf, 16 * nf); up("block_five_up", 16 * nf, 8 * nf)
+    block("block_six", 3, 8 * nf, 8 * nf); up("block_six_up", 8 * nf, 4 * nf)
+    block("block_seven", 3, 4 * nf, 4 * nf); up("block_seven_up", 4 * nf, 2 * nf)
+    block("block_eight", 2, 2 * nf, 2 * nf); up("block_eight_up", 2 * nf, nf)
+    block("block_nine", 1, nf, nf)
+    spec["out_conv.weight"] = (n_classes, nf, 1, 1, 1)
+    spec["out_conv.bias"] = (n_classes,)
+    _projection_spec(spec, 16 * nf)
+    return spec
+
+
+def unet_param_spec(in_ch=1, n_classes=2):
+    """UNet3D.__init__ registration order (UNet3D_contrastive.py:222-267), feature_scale=4."""
+    spec = OrderedDict()
+    f = UNET_FILTERS
+
+    def uc(prefix, cin, cout):
+        spec[f"{prefix}.conv1.0.weight"] = (cout, cin, 3, 3, 3)
+        spec[f"{prefix}.conv1.0.bias"] = (cout,)
+        spec[f"{prefix}.conv2.0.weight"] = (cout, cout, 3, 3, 3)
+        spec[f"{prefix}.conv2.0.bias"] = (cout,)
+
+    uc("conv1", in_ch, f[0]); uc("conv2", f[0], f[1]); uc("conv3", f[1], f[2]); uc("conv4", f[2], f[3])
+    uc("center", f[3], f[4])
+    uc("up_concat4.conv", f[4] + f[3], f[3]); uc("up_concat3.conv", f[3] + f[2], f[2])
+    uc("up_concat2.conv", f[2] + f[1], f[1]); uc("up_concat1.conv", f[1] + f[0], f[0])
+    spec["final.weight"] = (n_classes, f[0], 1, 1, 1)
+    spec["final.bias"] = (n_classes,)
+    spec["out_conv2.weight"] = (n_classes, f[0], 1, 1, 1)
+    spec["out_conv2.bias"] = (n_classes,)
+    _projection_spec(spec, f[4])
+    return spec
+
+
+def param_spec(net_type, in_ch=1, n_classes=2, normalization="groupnorm"):
+    if net_type == "vnet":
+        return vnet_param_spec(in_ch, n_classes, normalization)
+    if net_type == "unet_3D":
+        return unet_param_spec(in_ch, n_classes)
+    raise ValueError(f"unknown net_type {net_type!r}")
+
+
+# --------------------------------------------------------------------------------------
+class DropoutSpec:
+    """How the dropout sites draw their masks.
+
+    mode "off"    : identity (eval / parity runs with p = 0)
+    mode "mask"   : explicit keep-masks in ``masks`` (parity tests feed the oracle's masks)
+                    V-Net keys "drop5", "drop9": (B, C) ; U-Net keys "drop_center", "drop_up1": NDHWC-shaped
+    mode "philox" : on-device counter RNG, (seed, offset); offset must change every step
+    """
+
+    def __init__(self, mode="off", masks=None, seed=0, offset=0):
+        self.mode, self.masks, self.seed, self.offset = mode, masks or {}, seed, offset
+
+
+class Engine:
+    def __init__(self, net_type: str, params: Dict[str, torch.Tensor], grads: Optional[Dict[str, torch.Tensor]] = None,
+                 buffers: Optional[Dict[str, torch.Tensor]] = None, dtype=torch.float32, scale_factor=2,
+                 normalization="groupnorm"):
+        if net_type == "vnet" and normalization not in ("groupnorm", "instancenorm"):
+            raise NotImplementedError("the HIP V-Net supports normalization='groupnorm' (north-star) or 'instancenorm'")
+        self.net_type, self.p, self.g, self.buf = net_type, params, grads, buffers or {}
+        self.dtype, self.scale_factor, self.normalization = dtype, scale_factor, normalization
+        self.gen = 0                 # bump whenever parameter values change (invalidates packed weights)
+        self._packed = {}
+        self.tape = []
+        self.G = {}
+
+    # ---------------------------------------------------------------- packed-weight cache
+    def params_changed(self):
+        self.gen += 1
+
+    def _pk(self, key, fn):
+        hit = self._packed.get(key)
+        if hit is not None and hit[0] == self.gen:
+            return hit[1]
+        buf = fn(hit[1] if hit is not None else None)
+        self._packed[key] = (self.gen, buf)
+        return buf
+
+    # ---------------------------------------------------------------- gradient bookkeeping
+    def _take(self, t):
+        return self.G.pop(id(t))
+
+    def _give(self, t, g):
+        cur = self.G.get(id(t))
+        self.G[id(t)] = g if cur is None else ops.add(cur, g)
+
+    # ---------------------------------------------------------------- conv layers
+    def _conv(self, name, x, kind, need_gx=True, out_dtype=None):
+        """kind: k3 | k2s2 | deconv | 1x1.  Weight layouts as in torch (Conv3d: (Co,Ci,k..); ConvTranspose3d: (Ci,Co,k..))."""
+        w, b = self.p[name + ".weight"], self.p[name + ".bias"]
+        dtype = self.dtype
+        if kind == "deconv":
+            Cin, Cout = w.shape[0], w.shape[1]
+        else:
+            Cout, Cin = w.shape[0], w.shape[1]
+        T = {"k3": 27, "k2s2": 8, "deconv": 8, "1x1": 1}[kind]
+        mode = {"k3": CONV_K3, "k2s2": CONV_K2S2, "deconv": CONV_1X1, "1x1": CONV_1X1}[kind]
+        gq = 8 if dtype == torch.bfloat16 else 4
+        skinny = (Cin % gq != 0) or (Cout % 16 != 0)
+        out_dtype = out_dtype or dtype
+        if skinny:
+            assert kind in ("k3", "1x1"), "skinny path only for the first conv and the 1x1 heads"
+            wt = self._pk((name, "tcn"), lambda o: ops.pack_tcn(w, T, Cin, Cout, Cout, 1, T, 0, Cin * T, out=o))
+            y = ops.conv_direct(x, wt, b, mode, Cout, out_dtype)
+        elif kind == "deconv":
+            wf = self._pk((name, "f"), lambda o: ops.pack_bfrag(w, dtype, 1, Cin, 8 * Cout, Cout, 0, Cout * 8, 1, 8, out=o))
+            y = ops.conv_gemm(x, wf, b, CONV_1X1, 8 * Cout, Cout, scatter=True)
+        else:
+            wf = self._pk((name, "f"), lambda o: ops.pack_bfrag(w, dtype, T, Cin, Cout, Cout, 1, T, 0, Cin * T, out=o))
+            y = ops.conv_gemm(x, wf, b, mode, Cout, Cout)
+
+        if self.recording:
+            def bwd():
+                gy = self._take(y)
+                gw, gb = self.g[name + ".weight"], self.g[name + ".bias"]
+                ops.colsum(gy, gb)
+                if kind == "deconv":   # dW[ci][co][t] = sum_m x[m,ci] * gy[2m+t,co]
+                    ops.conv_wgrad(gy, x, gw, CONV_K2S2, 1, 8, Cout * 8)
+                else:
+                    ops.conv_wgrad(x, gy, gw, mode, 1 if T > 1 else 0, T, Cin * T)
+                if not need_gx:
+                    return
+                cur = self.G.get(id(x))
+                if skinny:             # 1x1 head: gx[m,ci] = sum_co gy[m,co] W[co][ci]
+                    wd = self._pk((name, "tcn_d"), lambda o: ops.pack_tcn(w, 1, Cout, Cin, Cin, 0, Cin, 0, 1, out=o))
+                    gx = ops.conv_direct(gy, wd, None, CONV_1X1, Cin, x.dtype, out=cur, accumulate=cur is not None)
+                elif kind == "k3":     # conv with flipped taps and transposed channels
+                    wd = self._pk((name, "d"), lambda o: ops.pack_bfrag(w, dtype, 27, Cout, Cin, Cin, 1, Cin * 27, 0, 27, flip=True, out=o))
+                    gx = ops.conv_gemm(gy, wd, None, CONV_K3, Cin, Cin, out=cur, accumulate=cur is not None)
+                elif kind == "k2s2":   # scatter: gx[2m+t, ci] = sum_co gy[m,co] W[co][ci][t]
+                    wd = self._pk((name, "d"), lambda o: ops.pack_bfrag(w, dtype, 1, Cout, 8 * Cin, Cin, 0, Cin * 8, 1, 8, out=o))
+                    gx = ops.conv_gemm(gy, wd, None, CONV_1X1, 8 * Cin, Cin, scatter=True, out=cur, accumulate=cur is not None)
+                elif kind == "deconv":  # gather: gx[m, ci] = sum_{t,co} gy[2m+t,co] W[ci][co][t]
+                    wd = self._pk((name, "d"), lambda o: ops.pack_bfrag(w, dtype, 8, Cout, Cin, Cin, 1, 8, 0, Cout * 8, out=o))
+                    gx = ops.conv_gemm(gy, wd, None, CONV_K2S2, Cin, Cin, out=cur, accumulate=cur is not None)
+                else:                  # 1x1
+                    wd = self._pk((name, "d"), lambda o: ops.pack_bfrag(w, dtype, 1, Cout, Cin, Cin, 0, Cin, 0, 1, out=o))
+                    gx = ops.conv_gemm(gy, wd, None, CONV_1X1, Cin, Cin, out=cur, accumulate=cur is not None)
+                self.G[id(x)] = gx
+            self.tape.append(bwd)
+        return y
+
+    # ---------------------------------------------------------------- norm (+ReLU, +skip)
+    def _norm(self, prefix, z, kind, relu=True, skip=None, training=True):
+        B, C = z.shape[0], z.shape[-1]
+        V = z.numel() // (B * C)
+        gamma = beta = None
+        rm = rv = None
+        if kind == "gn":
+            Nb, G = B, 16
+            gamma, beta = self.p[prefix + ".weight"], self.p[prefix + ".bias"]
+        elif kind == "in":
+            Nb, G = B, C
+        elif kind == "bn":
+            Nb, G, V = 1, C, B * V
+            gamma, beta = self.p[prefix + ".weight"], self.p[prefix + ".bias"]
+            rm, rv = self.buf.get(prefix + ".running_mean"), self.buf.get(prefix + ".running_var")
+        else:
+            raise ValueError(kind)
+        if kind == "bn" and not training:
+            # eval-mode BatchNorm (ISLES teacher, train_DyCON_ISLES22.py:114): running statistics
+            stats = torch.stack([rm, torch.rsqrt(rv + 1e-5)], 1).reshape(-1).contiguous()
+        else:
+            upd = kind == "bn" and training and self.update_bn
+            stats = ops.norm_stats(z, Nb, V, C, G, 1e-5, rm if upd else None, rv if upd else None, 0.1)
+            if upd and prefix + ".num_batches_tracked" in self.buf:
+                self.buf[prefix + ".num_batches_tracked"] += 1
+        # z is kept: the ReLU is not invertible, so the backward needs the pre-norm tensor (xhat of the
+        # clamped voxels still enters the group means)
+        y = ops.norm_apply(z, stats, Nb, V, C, G, gamma, beta, relu, skip)
+        if self.recording:
+            def bwd():
+                gy = self._take(y)
+                if skip is not None:
+                    self._give(skip, gy)
+                dg = self.g[prefix + ".weight"] if gamma is not None else None
+                db = self.g[prefix + ".bias"] if beta is not None else None
+                gz = ops.norm_bwd(z, False, gy, stats, Nb, V, C, G, gamma, beta, relu, dg, db)
+                self._give(z, gz)
+            self.tape.append(bwd)
+        return y
+
+    # ---------------------------------------------------------------- dropout sites
+    def _drop_channels(self, x, key, p, site):
+        d = self.dropout
+        if d.mode == "off":
+            return x
+        if d.mode == "mask":
+            m = d.masks.get(key)
+            if m is None:
+                return x
+            scale = (m.to(torch.float32) / (1.0 - p)).contiguous().reshape(-1)   # tiny (B*C) host-provided mask
+        else:
+            scale = ops.channel_mask_philox(x.shape[0] * x.shape[-1], p, d.seed, d.offset + site * (1 << 20), x.device)
+        y = ops.scale_channels(x, scale)
+        if self.recording:
+            def bwd():
+                self._give(x, ops.scale_channels(self._take(y), scale))
+            self.tape.append(bwd)
+        return y
+
+    def _drop_elements(self, x, key, p, site):
+        d = self.dropout
+        if d.mode == "off":
+            return x
+        if d.mode == "mask":
+            m = d.masks.get(key)
+            if m is None:
+                return x
+            f = lambda t: ops.mul_mask(t, m, 1.0 / (1.0 - p))   # noqa: E731
+        else:
+            off = d.offset + site * (1 << 40)
+            f = lambda t: ops.dropout_philox(t, p, d.seed, off)  # noqa: E731
+        y = f(x)
+        if self.recording:
+            def bwd():
+                self._give(x, f(self._take(y)))
+            self.tape.append(bwd)
+        return y
+
+    # ---------------------------------------------------------------- feature head
+    def _head(self, center, training):
+        """UNet3D_contrastive.py:261-267, 308-310: trilinear x scale (align_corners=True) -> 1x1 -> BN -> ReLU -> 1x1 -> BN."""
+        B, d, h, w, C = center.shape
+        s = self.scale_factor
+        c = ops.trilinear_fwd(center, (d * s, h * s, w * s), True)
+        if self.recording:
+            def bwd():
+                self._give(center, ops.trilinear_bwd(self._take(c), center.shape, True))
+            self.tape.append(bwd)
+        hdn = self._conv("projection.0", c, "1x1")
+        hdn = self._norm("projection.1", hdn, "bn", relu=True, training=training)
+        out = self._conv("projection.3", hdn, "1x1")
+        return self._norm("projection.4", out, "bn", relu=False, training=training)
+
+    # ---------------------------------------------------------------- V-Net
+    def _vnet(self, x, training):
+        nk = "gn" if self.normalization == "groupnorm" else "in"
+
+        def block(name, t, n, first=False):
+            for i in range(n):
+                t = self._conv(f"{name}.conv.{3 * i}", t, "k3", need_gx=not (first and i == 0))
+                t = self._norm(f"{name}.conv.{3 * i + 1}", t, nk)
+            return t
+
+        def down(name, t):
+            return self._norm(f"{name}.conv.1", self._conv(f"{name}.conv.0", t, "k2s2"), nk)
+
+        def up(name, t, skip):
+            return self._norm(f"{name}.conv.1", self._conv(f"{name}.conv.0", t, "deconv"), nk, skip=skip)
+
+        x1 = block("block_one", x, 1, first=True)
+        x2 = block("block_two", down("block_one_dw", x1), 2)
+        x3 = block("block_three", down("block_two_dw", x2), 3)
+        x4 = block("block_four", down("block_three_dw", x3), 3)
+        x5 = block("block_five", down("block_four_dw", x4), 3)
+        x5 = self._drop_channels(x5, "drop5", 0.5, 0)                       # VNet.py:195-196
+        u = up("block_five_up", x5, x4)
+        u = up("block_six_up", block("block_six", u, 3), x3)
+        u = up("block_seven_up", block("block_seven", u, 3), x2)
+        u = up("block_eight_up", block("block_eight", u, 2), x1)
+        x9 = self._drop_channels(block("block_nine", u, 1), "drop9", 0.5, 1)   # VNet.py:225-226
+        logits = self._conv("out_conv", x9, "1x1", out_dtype=torch.float32)
+        feats = self._head(x5, training)
+        return logits, feats, None
+
+    # ---------------------------------------------------------------- U-Net
+    def _unet(self, x, training, want_sdf):
+        def uconv(prefix, t, first=False):
+            t = self._norm(None, self._conv(prefix + ".conv1.0", t, "k3", need_gx=not first), "in")
+            return self._norm(None, self._conv(prefix + ".conv2.0", t, "k3"), "in")
+
+        def pool(t):
+            y, idx = ops.maxpool2_fwd(t)
+            if self.recording:
+                def bwd():
+                    self._give(t, ops.maxpool2_bwd(self._take(y), idx, t.shape))
+                self.tape.append(bwd)
+            return y
+
+        def upcat(prefix, skip, low):
+            B, D, H, W, C1 = skip.shape
+            C2 = low.shape[-1]
+            cat = torch.empty((B, D, H, W, C1 + C2), dtype=skip.dtype, device=skip.device)
+            ops.copy_channels(skip, 0, cat, 0, C1)                       # torch.cat([skip, up], 1)  (networks/utils.py:276)
+            ops.trilinear_fwd(low, (D, H, W), False, out=cat, coff=C1)   # nn.Upsample(2, 'trilinear')  (networks/utils.py:264)
+            if self.recording:
+                def bwd():
+                    gc = self._take(cat)
+                    gs = torch.empty(skip.shape, dtype=gc.dtype, device=gc.device)
+                    ops.copy_channels(gc, 0, gs, 0, C1)
+                    self._give(skip, gs)
+                    self._give(low, ops.trilinear_bwd(gc, low.shape, False, coff=C1))
+                self.tape.append(bwd)
+            return uconv(prefix + ".conv", cat)
+
+        c1 = uconv("conv1", x, first=True)
+        c2 = uconv("conv2", pool(c1))
+        c3 = uconv("conv3", pool(c2))
+        c4 = uconv("conv4", pool(c3))
+        center = self._drop_elements(uconv("center", pool(c4)), "drop_center", 0.3, 0)
+        u4 = upcat("up_concat4", c4, center)
+        u3 = upcat("up_concat3", c3, u4)
+        u2 = upcat("up_concat2", c2, u3)
+        u1 = self._drop_elements(upcat("up_concat1", c1, u2), "drop_up1", 0.3, 1)
+        logits = self._conv("out_conv2", u1, "1x1", out_dtype=torch.float32)
+        feats = self._head(center, training)
+        sdf = None
+        if want_sdf:   # tanh(final(up1)) -- returned for API parity, discarded by the training step
+            rec, self.recording = self.recording, False
+            sdf = ops.tanh(self._conv("final", u1, "1x1", out_dtype=torch.float32))
+            self.recording = rec
+        return logits, feats, sdf
+
+    # ---------------------------------------------------------------- public
+    def forward(self, x, training=True, record=True, dropout: Optional[DropoutSpec] = None, update_bn=True,
+                want_sdf=False):
+        """x: (B, D, H, W, Cin) fp32 or ``dtype``.  Returns (logits fp32 (B,D,H,W,2), feats (B,d,h,w,256), sdf|None)."""
+        assert x.dim() == 5 and x.is_contiguous()
+        self.recording = bool(record)
+        self.update_bn = update_bn
+        self.dropout = dropout or DropoutSpec("off")
+        self.tape, self.G = [], {}
+        if x.dtype != self.dtype:
+            x = ops.cast(x, self.dtype)
+        if self.net_type == "vnet":
+            logits, feats, sdf = self._vnet(x, training)
+            if want_sdf:
+                sdf = ops.tanh(logits)
+        else:
+            logits, feats, sdf = self._unet(x, training, want_sdf)
+        self._out = (logits, feats)
+        return logits, feats, sdf
+
+    def backward(self, g_logits: Optional[torch.Tensor], g_feats: Optional[torch.Tensor]):
+        """Seeds the two outputs' gradients and replays the tape.  Parameter gradients are WRITTEN (not
+        accumulated) into ``grads``; parameters that receive no gradient (UNet3D ``final.*``) are left untouched."""
+        logits, feats = self._out
+        if g_logits is None:
+            g_logits = torch.zeros_like(logits)
+        if g_feats is None:
+            g_feats = torch.zeros_like(feats)
+        self.G[id(logits)] = g_logits
+        self.G[id(feats)] = g_feats
+        for fn in reversed(self.tape):
+            fn()
+        self.tape, self.G = [], {}

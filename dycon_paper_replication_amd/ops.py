@@ -1,0 +1,391 @@
+"""Tensor-level wrappers over the C ABI (include/dycon_hip.h).
+
+Every function takes/returns torch CUDA tensors and only enqueues HIP kernels on torch's current
+stream (no sync, graph-capturable).  Activations are NDHWC: shape (B, D, H, W, C), contiguous.
+PyTorch is used for device memory and streams only -- no torch math runs here.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from . import _lib
+from ._lib import BF16, CONV_1X1, CONV_K2S2, CONV_K3, F32, call, query
+
+_DT = {torch.float32: F32, torch.bfloat16: BF16}
+
+
+def dt(t: torch.Tensor) -> int:
+    try:
+        return _DT[t.dtype]
+    except KeyError:
+        raise TypeError(f"unsupported dtype {t.dtype}: the HIP path stores fp32 or bf16") from None
+
+
+def _s():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t: Optional[torch.Tensor]):
+    if t is None:
+        return None
+    assert t.is_cuda and t.is_contiguous(), "HIP ops need contiguous CUDA tensors"
+    return t.data_ptr()
+
+
+# ------------------------------------------------------------------ optional per-kernel timing (bench.py)
+class KernelProfiler:
+    """HIP-event timing of individual entry points on the launch stream (torch's current stream), with the
+    ALGORITHMIC bytes / flops of every launch (inputs + outputs read/written once, true K/N without padding)."""
+
+    def __init__(self):
+        self.rec = {}
+
+    def add(self, name, e0, e1, nbytes, flops):
+        self.rec.setdefault(name, []).append((e0, e1, nbytes, flops))
+
+    def summary(self):
+        out = {}
+        for name, rows in self.rec.items():
+            ms = sum(a.elapsed_time(b) for a, b, _, _ in rows)
+            out[name] = {"launches": len(rows), "ms": ms, "bytes": sum(r[2] for r in rows), "flops": sum(r[3] for r in rows)}
+        return out
+
+
+PROFILER: Optional[KernelProfiler] = None
+
+
+class _Region:
+    __slots__ = ("name", "nbytes", "flops", "e0")
+
+    def __init__(self, name, nbytes, flops):
+        self.name, self.nbytes, self.flops = name, nbytes, flops
+
+    def __enter__(self):
+        if PROFILER is not None:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+
+    def __exit__(self, *a):
+        if PROFILER is not None:
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record()
+            PROFILER.add(self.name, self.e0, e1, self.nbytes, self.flops)
+
+
+def _es(t):
+    return t.element_size()
+
+
+def _ws(nbytes: int, like: torch.Tensor) -> torch.Tensor:
+    return torch.empty(max(int(nbytes) // 4, 1), dtype=torch.float32, device=like.device)
+
+
+# ------------------------------------------------------------------ weight packing
+def pack_bfrag(w: torch.Tensor, dtype: torch.dtype, T, Cin, N, N0, s_t, s_c, s_n1, s_n0, flip=False, out=None):
+    d = _DT[dtype]
+    nbytes = query("dycon_bfrag_bytes", d, T, Cin, N)
+    if out is None:
+        out = torch.empty(nbytes // (2 if d == BF16 else 4), dtype=dtype, device=w.device)
+    call("dycon_pack_bfrag", _p(w), _p(out), d, T, Cin, N, N0, s_t, s_c, s_n1, s_n0, int(flip), _s())
+    return out
+
+
+def pack_tcn(w: torch.Tensor, T, Cin, N, N0, s_t, s_c, s_n1, s_n0, flip=False, out=None):
+    if out is None:
+        out = torch.empty(T * Cin * N, dtype=torch.float32, device=w.device)
+    call("dycon_pack_tcn", _p(w), _p(out), T, Cin, N, N0, s_t, s_c, s_n1, s_n0, int(flip), _s())
+    return out
+
+
+# ------------------------------------------------------------------ conv family
+def conv_gemm(x, wfrag, bias, mode, N, Cout, scatter=False, out=None, accumulate=False):
+    B, D, H, W, Cin = x.shape
+    if out is None:
+        assert not accumulate
+        if scatter:
+            shape = (B, 2 * D, 2 * H, 2 * W, Cout)
+        elif mode == CONV_K2S2:
+            shape = (B, D // 2, H // 2, W // 2, N)
+        else:
+            shape = (B, D, H, W, N)
+        out = torch.empty(shape, dtype=x.dtype, device=x.device)
+    taps = {CONV_K3: 27, CONV_K2S2: 8, CONV_1X1: 1}[mode]
+    rows = out.numel() // Cout if not scatter else x.numel() // Cin
+    with _Region("conv_gemm", (x.numel() + out.numel() * (2 if accumulate else 1)) * _es(x) + taps * Cin * N * _es(x),
+                 2 * rows * taps * Cin * N):
+        call("dycon_conv_gemm", _p(x), _p(wfrag), _p(bias), _p(out), dt(x), mode, int(scatter), int(accumulate),
+             B, D, H, W, Cin, N, Cout, _s())
+    return out
+
+
+def conv_direct(x, w_tcn, bias, mode, N, out_dtype, out=None, accumulate=False):
+    B, D, H, W, Cin = x.shape
+    if out is None:
+        assert not accumulate
+        shape = (B, D // 2, H // 2, W // 2, N) if mode == CONV_K2S2 else (B, D, H, W, N)
+        out = torch.empty(shape, dtype=out_dtype, device=x.device)
+    taps = {CONV_K3: 27, CONV_K2S2: 8, CONV_1X1: 1}[mode]
+    with _Region("conv_direct", x.numel() * _es(x) + out.numel() * _es(out), 2 * (out.numel() // N) * taps * Cin * N):
+        call("dycon_conv_direct", _p(x), dt(x), _p(w_tcn), _p(bias), _p(out), dt(out), mode, int(accumulate),
+             B, D, H, W, Cin, N, _s())
+    return out
+
+
+def conv_wgrad(x, gy, dw, mode, s_t, s_c, s_n):
+    """dw[t*s_t + c*s_c + n*s_n] = sum_rows x[src(row,t), c] * gy[row, n]; dw is an fp32 tensor (any shape)."""
+    B, D, H, W, Cin = x.shape
+    Cout = gy.shape[-1]
+    nbytes = query("dycon_conv_wgrad_workspace", mode, B, D, H, W, Cin, Cout)
+    ws = _ws(nbytes, x)
+    taps = {CONV_K3: 27, CONV_K2S2: 8, CONV_1X1: 1}[mode]
+    with _Region("conv_wgrad", x.numel() * _es(x) + gy.numel() * _es(gy) + taps * Cin * Cout * 4,
+                 2 * (gy.numel() // Cout) * taps * Cin * Cout):
+        call("dycon_conv_wgrad", _p(x), dt(x), _p(gy), dt(gy), _p(dw), mode, B, D, H, W, Cin, Cout, s_t, s_c, s_n,
+             _p(ws), ws.numel() * 4, _s())
+    return dw
+
+
+def colsum(x2d_like, out):
+    """out[c] = sum over all leading dims of x[..., c]."""
+    C = x2d_like.shape[-1]
+    rows = x2d_like.numel() // C
+    ws = _ws(query("dycon_colsum_workspace", rows, C), x2d_like)
+    with _Region("colsum", x2d_like.numel() * _es(x2d_like), x2d_like.numel()):
+        call("dycon_colsum", _p(x2d_like), dt(x2d_like), _p(out), rows, C, _p(ws), ws.numel() * 4, _s())
+    return out
+
+
+# ------------------------------------------------------------------ normalisation
+def norm_stats(x, Nb, V, C, G, eps=1e-5, running_mean=None, running_var=None, momentum=0.1):
+    stats = torch.empty(Nb * G * 2, dtype=torch.float32, device=x.device)
+    ws = _ws(query("dycon_norm_workspace", Nb, V, C), x)
+    with _Region("norm_stats", x.numel() * _es(x), 3 * x.numel()):
+        call("dycon_norm_stats", _p(x), dt(x), Nb, V, C, G, eps, _p(stats), _p(running_mean), _p(running_var), momentum,
+             _p(ws), ws.numel() * 4, _s())
+    return stats
+
+
+def norm_apply(x, stats, Nb, V, C, G, gamma=None, beta=None, relu=True, skip=None, out=None):
+    if out is None:
+        out = torch.empty_like(x)
+    with _Region("norm_apply", x.numel() * _es(x) * (3 if skip is not None else 2), 3 * x.numel()):
+        call("dycon_norm_apply", _p(x), _p(out), dt(x), Nb, V, C, G, _p(stats), _p(gamma), _p(beta), int(relu), _p(skip), _s())
+    return out
+
+
+def norm_bwd(src, from_y, gy, stats, Nb, V, C, G, gamma=None, beta=None, relu=True, dgamma=None, dbeta=None, out=None):
+    if out is None:
+        out = torch.empty_like(gy)
+    ws = _ws(query("dycon_norm_workspace", Nb, V, C), gy)
+    with _Region("norm_bwd", gy.numel() * _es(gy) * 5, 12 * gy.numel()):
+        call("dycon_norm_bwd", _p(src), int(from_y), _p(gy), _p(out), dt(gy), Nb, V, C, G, _p(stats), _p(gamma), _p(beta),
+             int(relu), _p(dgamma), _p(dbeta), _p(ws), ws.numel() * 4, _s())
+    return out
+
+
+# ------------------------------------------------------------------ data movement / pointwise
+def maxpool2_fwd(x):
+    B, D, H, W, C = x.shape
+    y = torch.empty((B, D // 2, H // 2, W // 2, C), dtype=x.dtype, device=x.device)
+    idx = torch.empty(y.shape, dtype=torch.uint8, device=x.device)
+    call("dycon_maxpool2_fwd", _p(x), _p(y), _p(idx), dt(x), B, D, H, W, C, _s())
+    return y, idx
+
+
+def maxpool2_bwd(gy, idx, in_shape):
+    B, D, H, W, C = in_shape
+    gx = torch.empty(in_shape, dtype=gy.dtype, device=gy.device)
+    call("dycon_maxpool2_bwd", _p(gy), _p(idx), _p(gx), dt(gy), B, D, H, W, C, _s())
+    return gx
+
+
+def trilinear_fwd(x, out_dhw, align_corners, out=None, coff=0):
+    B, D, H, W, C = x.shape
+    Do, Ho, Wo = out_dhw
+    if out is None:
+        out = torch.empty((B, Do, Ho, Wo, C), dtype=x.dtype, device=x.device)
+    call("dycon_trilinear_fwd", _p(x), _p(out), dt(x), B, D, H, W, Do, Ho, Wo, C, out.shape[-1], coff, int(align_corners), _s())
+    return out
+
+
+def trilinear_bwd(gy, in_shape, align_corners, coff=0):
+    B, D, H, W, C = in_shape
+    _, Do, Ho, Wo, ld = gy.shape
+    gx = torch.empty(in_shape, dtype=gy.dtype, device=gy.device)
+    call("dycon_trilinear_bwd", _p(gy), _p(gx), dt(gy), B, D, H, W, Do, Ho, Wo, C, ld, coff, int(align_corners), _s())
+    return gx
+
+
+def copy_channels(src, soff, dst, doff, C):
+    rows = src.numel() // src.shape[-1]
+    call("dycon_copy_channels", _p(src), src.shape[-1], soff, _p(dst), dst.shape[-1], doff, rows, C, dt(src), _s())
+    return dst
+
+
+def scale_channels(x, scale):
+    B, C = x.shape[0], x.shape[-1]
+    V = x.numel() // (B * C)
+    y = torch.empty_like(x)
+    call("dycon_scale_channels", _p(x), _p(scale), _p(y), dt(x), B, V, C, _s())
+    return y
+
+
+def mul_mask(x, mask, inv_keep):
+    y = torch.empty_like(x)
+    call("dycon_mul_mask", _p(x), _p(mask), inv_keep, _p(y), dt(x), x.numel(), _s())
+    return y
+
+
+def dropout_philox(x, p, seed, offset):
+    y = torch.empty_like(x)
+    call("dycon_dropout_philox", _p(x), _p(y), dt(x), x.numel(), p, seed, offset, _s())
+    return y
+
+
+def channel_mask_philox(n, p, seed, offset, device):
+    s = torch.empty(n, dtype=torch.float32, device=device)
+    call("dycon_channel_mask_philox", _p(s), n, p, seed, offset, _s())
+    return s
+
+
+def add_noise(x, noise=None, sigma=0.1, clip=0.2, seed=0, offset=0):
+    y = torch.empty_like(x)
+    call("dycon_add_noise", _p(x), _p(noise), _p(y), dt(x), x.numel(), sigma, clip, seed, offset, _s())
+    return y
+
+
+def tanh(x):
+    y = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+    call("dycon_tanh", _p(x), dt(x), _p(y), x.numel(), _s())
+    return y
+
+
+def cast(x, dtype):
+    y = torch.empty(x.shape, dtype=dtype, device=x.device)
+    call("dycon_cast", _p(x), dt(x), _p(y), _DT[dtype], x.numel(), _s())
+    return y
+
+
+def add(a, b=None, out=None):
+    if out is None:
+        out = torch.empty_like(a)
+    call("dycon_add", _p(a), _p(b), _p(out), dt(a), a.numel(), _s())
+    return out
+
+
+# ------------------------------------------------------------------ losses
+def _label_bytes(labels):
+    if labels.dtype == torch.int64:
+        return 8
+    if labels.dtype == torch.uint8:
+        return 1
+    raise TypeError("labels must be int64 or uint8")
+
+
+def seg_losses_fwd(s_logits, t_logits, labels, LB, beta):
+    """s/t_logits: (B, D, H, W, 2) fp32; returns sums (16 doubles on device)."""
+    B = s_logits.shape[0]
+    V = s_logits.numel() // (2 * B)
+    sums = torch.empty(16, dtype=torch.float64, device=s_logits.device)
+    call("dycon_seg_losses_fwd", _p(s_logits), _p(t_logits), _p(labels), _label_bytes(labels), B, LB, V, float(beta), _p(sums), _s())
+    return sums
+
+
+def seg_losses_bwd(s_logits, t_logits, labels, LB, beta, sums, coef, cons_kind=0):
+    B = s_logits.shape[0]
+    V = s_logits.numel() // (2 * B)
+    g = torch.empty_like(s_logits)
+    call("dycon_seg_losses_bwd", _p(s_logits), _p(t_logits), _p(labels), _label_bytes(labels), B, LB, V, float(beta), _p(sums),
+         _p(coef), cons_kind, _p(g), _s())
+    return g
+
+
+def seg_losses_finalize(sums, B, LB, V, beta):
+    vals = torch.empty(8, dtype=torch.float32, device=sums.device)
+    call("dycon_seg_losses_finalize", _p(sums), B, LB, V, float(beta), _p(vals), _s())
+    return vals
+
+
+def step_loss(vals, fecl, l_w, cons_w, u_w, dice_kind, cons_kind, nonfinite=None):
+    out = torch.empty(8, dtype=torch.float32, device=vals.device)
+    call("dycon_step_loss", _p(vals), _p(fecl), float(l_w), float(cons_w), float(u_w), dice_kind, cons_kind, _p(out),
+         _p(nonfinite), _s())
+    return out
+
+
+def l2norm_fwd(x, eps=1e-12):
+    C = x.shape[-1]
+    R = x.numel() // C
+    y = torch.empty_like(x)
+    norms = torch.empty(R, dtype=torch.float32, device=x.device)
+    call("dycon_l2norm_fwd", _p(x), _p(y), _p(norms), dt(x), R, C, eps, _s())
+    return y, norms
+
+
+def l2norm_bwd(y, norms, gy, eps=1e-12):
+    C = y.shape[-1]
+    gx = torch.empty_like(gy)
+    call("dycon_l2norm_bwd", _p(y), _p(norms), _p(gy), _p(gx), dt(y), y.numel() // C, C, eps, _s())
+    return gx
+
+
+def mask_pool(labels, k):
+    """labels (B, D, H, W) int64/uint8 -> (B, N) float mask = avg_pool3d(label, k) > 0.5."""
+    B, D, H, W = labels.shape
+    kd, kh, kw = (k, k, k) if isinstance(k, int) else k
+    m = torch.empty((B, (D // kd) * (H // kh) * (W // kw)), dtype=torch.float32, device=labels.device)
+    call("dycon_mask_pool", _p(labels), _label_bytes(labels), _p(m), B, D, H, W, kd, kh, kw, _s())
+    return m
+
+
+class FeclState:
+    __slots__ = ("out", "ws", "loss")
+
+
+def fecl_fwd(feat, teacher, mask, gambling, temperature, gamma, use_focal, cross_thresh, lambda_cross):
+    """feat/teacher (B, N, Dm) normalised rows; mask (B, N) float.  Returns (loss[1] fp32, state)."""
+    B, N, Dm = feat.shape
+    st = FeclState()
+    st.out = torch.empty(4, dtype=torch.float64, device=feat.device)
+    st.loss = torch.empty(1, dtype=torch.float32, device=feat.device)
+    st.ws = _ws(query("dycon_fecl_workspace", B, N), feat)
+    call("dycon_fecl_fwd", _p(feat), _p(teacher), _p(mask), _p(gambling), dt(feat), B, N, Dm, temperature, gamma,
+         int(use_focal), cross_thresh, lambda_cross, _p(st.out), _p(st.loss), _p(st.ws), st.ws.numel() * 4, _s())
+    return st.loss, st
+
+
+def fecl_finalize(st, rows, lambda_cross, has_teacher):
+    call("dycon_fecl_finalize", _p(st.out), float(rows), float(lambda_cross), int(bool(has_teacher)), _p(st.loss), _s())
+    return st.loss
+
+
+def set_scalars(dst, values):
+    v = [float(x) for x in values] + [0.0] * (8 - len(values))
+    call("dycon_set_scalars", _p(dst), len(values), *v, _s())
+    return dst
+
+
+def fecl_bwd(feat, teacher, mask, gambling, temperature, gamma, use_focal, cross_thresh, lambda_cross, st, coef):
+    B, N, Dm = feat.shape
+    g = torch.empty_like(feat)
+    call("dycon_fecl_bwd", _p(feat), _p(teacher), _p(mask), _p(gambling), dt(feat), B, N, Dm, temperature, gamma,
+         int(use_focal), cross_thresh, lambda_cross, _p(st.out), _p(coef), _p(g), _p(st.ws), st.ws.numel() * 4, _s())
+    return g
+
+
+# ------------------------------------------------------------------ optimiser
+def sumsq(g, out):
+    call("dycon_sumsq", _p(g), g.numel(), _p(out), _s())
+    return out
+
+
+def sgd_ema(p, g, mom, teacher, n_sgd, sumsq_t, max_norm, grad_scale, lr, momentum, weight_decay, ema_alpha, skip_flag=None):
+    call("dycon_sgd_ema", _p(p), _p(g), _p(mom), _p(teacher), n_sgd, p.numel(), _p(sumsq_t), max_norm, grad_scale, lr,
+         momentum, weight_decay, ema_alpha, _p(skip_flag), _s())
+
+
+def nonfinite_flag(x, flag):
+    call("dycon_nonfinite_flag", _p(x), _p(flag), _s())
+    return flag

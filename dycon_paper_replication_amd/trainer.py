@@ -1,0 +1,254 @@
+"""The DyCON training step on the MI355X -- code/train_DyCON_BraTS19.py:298-372 as one launch sequence.
+
+    noise -> student fwd -> teacher fwd -> fused voxel losses + FeCL -> backward -> (RCCL all-reduce)
+          -> clip + SGD + EMA (one fused pass over flat arenas) -> weight repack
+
+Everything between the input tensors and the updated arenas is HIP kernels from libdycon_hip.so
+enqueued on the current stream; the host only computes the reference's scalar schedules
+(adaptive beta, consistency ramp, FeCL threshold ramp, EMA alpha, poly LR).  The only device->host
+read is the reference's own NaN/Inf guard (:360-362), one int per step (``strict_nan_check``).
+
+Multi-GPU (one process per GPU, ``torch.distributed`` backend "nccl" == RCCL over xGMI): the batch
+is sharded [labelled | unlabelled] per rank; one all-reduce of the flat gradient arena after the
+backward, plus two tiny all-reduces (16 + 4 doubles) that keep the reference's batch-global
+semantics of the Dice ratio and of the FeCL cross-branch ratio.
+"""
+from __future__ import annotations
+
+import math
+from collections import OrderedDict
+from dataclasses import dataclass
+from typing import Dict, Optional
+
+import torch
+
+from . import ops
+from .engine import DropoutSpec, Engine, param_spec, projection_buffers
+from .networks.net_factory_3d import net_factory_3d
+from .utils import ramps
+from .utils.dycon_losses import adaptive_beta, sigmoid_rampup
+
+
+@dataclass
+class TrainConfig:
+    """Flag names and defaults of code/train_DyCON_BraTS19.py:26-67."""
+    model: str = "vnet"                 # "vnet" | "unet_3D"
+    normalization: str = "groupnorm"    # V-Net only
+    max_iterations: int = 20000
+    batch_size: int = 8                 # per process
+    labeled_bs: int = 4                 # per process
+    base_lr: float = 0.01
+    labelnum: int = 25
+    ema_decay: float = 0.99
+    consistency: float = 0.1
+    consistency_type: str = "mse"       # "mse" | "kl"
+    consistency_rampup: float = 200.0
+    gamma: float = 2.0
+    beta_min: float = 0.5
+    beta_max: float = 5.0
+    s_beta: Optional[float] = None
+    temp: float = 0.6
+    l_weight: float = 1.0
+    u_weight: float = 0.5
+    use_focal: int = 1
+    use_teacher_loss: int = 1
+    feature_scaler: int = 2
+    seed: int = 1337
+    rampup_epochs: int = 1500           # FeCLoss(rampup_epochs=1500), train_DyCON_BraTS19.py:287-288
+    momentum: float = 0.9
+    weight_decay: float = 1e-4
+    max_grad_norm: float = 1.0
+    dice_variant: str = "fg"            # "fg": losses.dice_loss (BraTS/Pancreas) | "multiclass": losses.DiceLoss (ISLES)
+    teacher_mode: str = "train"         # "train" (BraTS/Pancreas, :264) | "eval" (ISLES, train_DyCON_ISLES22.py:114)
+    poly_lr: bool = False               # ISLES: lr = base*(1 - it/max)^0.9 after each step (train_DyCON_ISLES22.py:322-324)
+    dtype: torch.dtype = torch.bfloat16  # activation storage of the HIP kernels (fp32 = parity mode)
+    strict_nan_check: bool = True       # read the NaN/Inf flag every step, as the reference does
+    global_batch_losses: bool = True    # DDP: all-reduce the Dice / FeCL-cross sums (exact global-batch semantics)
+
+
+class DyconTrainer:
+    def __init__(self, cfg: TrainConfig, device="cuda:0", student_init: Optional[Dict[str, torch.Tensor]] = None,
+                 teacher_init: Optional[Dict[str, torch.Tensor]] = None, process_group=None):
+        self.cfg, self.device = cfg, torch.device(device)
+        self.pg = process_group
+        self.world = torch.distributed.get_world_size(process_group) if process_group is not None else 1
+        self.rank = torch.distributed.get_rank(process_group) if process_group is not None else 0
+        spec = param_spec(cfg.model, 1, 2, cfg.normalization)
+        # parameters the loss never reaches keep grad=None in the reference and are skipped by
+        # clip_grad_norm_/SGD (weight decay included): put them behind the SGD range of the arena
+        nograd = [k for k in spec if k.startswith("final.")]
+        order = [k for k in spec if k not in nograd] + nograd
+        sizes = {k: int(math.prod(spec[k])) for k in spec}
+        pad = lambda n: (n + 3) // 4 * 4      # keep every view 16-byte aligned  # noqa: E731
+        offs, off = {}, 0
+        for k in order:
+            if k == (nograd[0] if nograd else None):
+                self.n_sgd = off
+            offs[k] = off
+            off += pad(sizes[k])
+        if not nograd:
+            self.n_sgd = off
+        self.n_all = off
+        f32 = dict(dtype=torch.float32, device=self.device)
+        self.flat_p = torch.zeros(self.n_all, **f32)
+        self.flat_t = torch.zeros(self.n_all, **f32)
+        self.flat_g = torch.zeros(self.n_all, **f32)
+        self.flat_m = torch.zeros(self.n_all, **f32)
+        view = lambda flat, k: flat[offs[k]:offs[k] + sizes[k]].view(spec[k])  # noqa: E731
+        self.names = list(spec)
+        self.p = OrderedDict((k, view(self.flat_p, k)) for k in spec)
+        self.t = OrderedDict((k, view(self.flat_t, k)) for k in spec)
+        self.g = OrderedDict((k, view(self.flat_g, k)) for k in spec)
+
+        # nn.Module shells (state_dict / eval-mode inference); their parameters alias the arenas
+        self.model = net_factory_3d(cfg.model, 1, 2, cfg.feature_scaler, dtype=cfg.dtype, normalization=cfg.normalization)
+        self.ema_model = net_factory_3d(cfg.model, 1, 2, cfg.feature_scaler, dtype=cfg.dtype, normalization=cfg.normalization)
+        g0 = torch.Generator().manual_seed(cfg.seed)
+        for mod, init, arena in ((self.model, student_init, self.p), (self.ema_model, teacher_init, self.t)):
+            if init is None:     # two independently initialised nets, as create_model() x2 (:212-230); same on every rank
+                init = {k: mod._init_tensor(k, spec[k], g0) for k in spec}
+            mod.to(self.device)
+            for k, prm in mod.named_parameters():
+                arena[k].copy_(init[k].to(self.device, torch.float32))
+                prm.data = arena[k]
+                if mod is self.ema_model:
+                    prm.requires_grad_(False)   # `param.detach_()` in create_model(ema=True), :220-224
+            for k, b in mod.named_buffers():
+                if init is not None and k in init:
+                    b.copy_(init[k].to(self.device))
+        self.s_buf = dict(self.model.named_buffers())
+        self.t_buf = dict(self.ema_model.named_buffers())
+        self.s_eng = Engine(cfg.model, self.p, self.g, self.s_buf, cfg.dtype, cfg.feature_scaler, cfg.normalization)
+        self.t_eng = Engine(cfg.model, self.t, None, self.t_buf, cfg.dtype, cfg.feature_scaler, cfg.normalization)
+        self.iter_num = 0
+        self.lr = cfg.base_lr * (self.world if self.world > 1 else 1)   # LR x n_gpu, train_DyCON_BraTS19.py:108-110
+        self.base_lr = self.lr
+        self.iters_per_epoch = max(cfg.labelnum // max(cfg.labeled_bs * self.world, 1), 1)
+        self.max_epoch = cfg.max_iterations // self.iters_per_epoch + 1
+        self.sumsq = torch.zeros(1, dtype=torch.float64, device=self.device)
+        self.flag = torch.zeros(1, dtype=torch.int32, device=self.device)
+        self.coef = torch.zeros(8, dtype=torch.float32, device=self.device)
+        self.skipped_steps = 0
+
+    # ------------------------------------------------------------------ schedules (host scalars)
+    def epoch_of(self, it):
+        return it // self.iters_per_epoch
+
+    def beta_at(self, epoch):
+        c = self.cfg
+        return c.s_beta if c.s_beta is not None else adaptive_beta(epoch, self.max_epoch, c.beta_max, c.beta_min)
+
+    def consistency_weight(self, it):
+        return self.cfg.consistency * ramps.sigmoid_rampup(it // 150, self.cfg.consistency_rampup)
+
+    # ------------------------------------------------------------------ the step
+    def step(self, volume, label, noise=None, s_drop: Optional[DropoutSpec] = None, t_drop: Optional[DropoutSpec] = None,
+             epoch: Optional[int] = None, beta: Optional[float] = None):
+        """volume (B,1,D,H,W) fp32, label (B,D,H,W) int64|uint8, both on the device.  The first
+        ``labeled_bs`` samples are the labelled ones (TwoStreamBatchSampler order, dataloaders/brats19.py:309-314).
+
+        noise / s_drop / t_drop: explicit randomness for parity tests; default = on-device Philox."""
+        c = self.cfg
+        B, LB = volume.shape[0], c.labeled_bs
+        D, H, W = volume.shape[2:]
+        V = D * H * W
+        it = self.iter_num
+        epoch = self.epoch_of(it) if epoch is None else epoch
+        beta = self.beta_at(epoch) if beta is None else beta
+        cw = self.consistency_weight(it)
+        thr = sigmoid_rampup(epoch, c.rampup_epochs, 0.3, 0.5)
+        seed = (c.seed * 1000003 + self.rank) & 0x7FFFFFFFFFFFFFFF
+        if s_drop is None:
+            s_drop = DropoutSpec("philox", seed=seed, offset=(2 * it + 0) << 42)
+        if t_drop is None:
+            t_drop = DropoutSpec("philox", seed=seed, offset=(2 * it + 1) << 42) if c.teacher_mode == "train" else DropoutSpec("off")
+
+        x = volume.reshape(B, D, H, W, 1) if volume.is_contiguous() else volume.contiguous().reshape(B, D, H, W, 1)
+        x_t = ops.add_noise(x, None if noise is None else noise.contiguous(), 0.1, 0.2, seed ^ 0x5DEECE66D, it << 32)  # :301-302
+
+        s_logits, s_feat, _ = self.s_eng.forward(x, training=True, record=True, dropout=s_drop, update_bn=True)   # :304
+        t_train = c.teacher_mode == "train"
+        t_logits, t_feat, _ = self.t_eng.forward(x_t, training=t_train, record=False, dropout=t_drop, update_bn=t_train)  # :305-306
+
+        # ---- losses (:308-357)
+        world = self.world
+        glob = world > 1 and c.global_batch_losses
+        sums = ops.seg_losses_fwd(s_logits, t_logits, label, LB, beta)
+        s_emb, s_nrm = ops.l2norm_fwd(s_feat.reshape(B, -1, s_feat.shape[-1]))          # :316-319
+        t_emb, _ = ops.l2norm_fwd(t_feat.reshape(B, -1, t_feat.shape[-1]))              # :321-323
+        k = (D // s_feat.shape[1], H // s_feat.shape[2], W // s_feat.shape[3])
+        mask = ops.mask_pool(label, k)                                                   # :326-330
+        teacher_emb = t_emb if c.use_teacher_loss else None
+        fargs = (s_emb, teacher_emb, mask, None, c.temp, c.gamma, bool(c.use_focal), thr)
+        f_loss, fst = ops.fecl_fwd(*fargs, 1.0)
+        gw = 1
+        if glob:
+            # Dice is a ratio of batch-GLOBAL sums (losses.py:11-14) and the FeCL cross branch a global sum over a
+            # global count (dycon_losses.py:229): exchange the 16 + 4 accumulators, then finalise on every rank
+            torch.distributed.all_reduce(sums, group=self.pg)
+            torch.distributed.all_reduce(fst.out, group=self.pg)
+            f_loss = ops.fecl_finalize(fst, B * world * s_emb.shape[1], 1.0, teacher_emb is not None)
+            gw = world
+        vals = ops.seg_losses_finalize(sums, B * gw, LB * gw, V, beta)
+        dice_kind = 0 if c.dice_variant == "fg" else 1
+        cons_kind = 0 if c.consistency_type == "mse" else 1
+        out = ops.step_loss(vals, f_loss, c.l_weight, cw, c.u_weight, dice_kind, cons_kind, self.flag)   # :355-362
+
+        # ---- backward (:364-365).  coef = d total / d (ce, dice_fg, dice_mc, cons, uncl | fecl).
+        # Means over equal shards (CE, cons, UnCL, FeCL student part) become global through the 1/world arena average;
+        # the two global-ratio terms are differentiated w.r.t. LOCAL voxels and must be SUMMED over ranks -> x world.
+        ops.set_scalars(self.coef, [c.l_weight, c.l_weight * (1 - dice_kind) * gw, c.l_weight * dice_kind * gw, cw,
+                                    c.u_weight, c.u_weight])
+        g_logits = ops.seg_losses_bwd(s_logits, t_logits, label, LB, beta, sums, self.coef, cons_kind)
+        g_emb = ops.fecl_bwd(*fargs, float(gw), fst, self.coef[5:6])
+        g_feat = ops.l2norm_bwd(s_emb, s_nrm, g_emb).reshape(s_feat.shape)
+        self.s_eng.backward(g_logits, g_feat)
+
+        # ---- all-reduce, clip, SGD, EMA (:368-372)
+        if world > 1:
+            torch.distributed.all_reduce(self.flat_g, group=self.pg)
+        self.sumsq.zero_()
+        ops.sumsq(self.flat_g[: self.n_sgd], self.sumsq)
+        alpha = min(1 - 1 / (it + 1), c.ema_decay)
+        ops.sgd_ema(self.flat_p, self.flat_g, self.flat_m, self.flat_t, self.n_sgd, self.sumsq, c.max_grad_norm, 1.0 / world,
+                    self.lr, c.momentum, c.weight_decay, alpha, self.flag)
+        self.s_eng.params_changed()
+        self.t_eng.params_changed()
+        self.model.params_changed()
+        self.ema_model.params_changed()
+
+        skipped = False
+        if c.strict_nan_check:
+            skipped = bool(self.flag.item())     # the reference's own per-step sync (:360)
+        if skipped:
+            self.skipped_steps += 1              # `continue`: no update happened, iter_num unchanged
+        else:
+            if c.poly_lr:
+                self.lr = self.base_lr * (1.0 - it / c.max_iterations) ** 0.9
+            self.iter_num += 1
+        return {"loss": out[0], "ce": out[1], "dice": out[2], "cons": out[3], "fecl": out[4], "uncl": out[5],
+                "cons_weight": cw, "beta": beta, "grad_sumsq": self.sumsq, "skipped": skipped,
+                "s_logits": s_logits, "t_logits": t_logits, "s_feat": s_feat, "t_feat": t_feat, "mask": mask}
+
+    # ------------------------------------------------------------------ checkpoints (reference contract)
+    def state_dict(self):
+        """Student weights under the reference's keys (what train_DyCON_BraTS19.py:411-418 saves)."""
+        return OrderedDict((k, v.detach().clone()) for k, v in self.model.state_dict().items())
+
+    def teacher_state_dict(self):
+        return OrderedDict((k, v.detach().clone()) for k, v in self.ema_model.state_dict().items())
+
+    def full_state(self):
+        """Everything needed to resume (the reference cannot resume: SURVEY.md section 5)."""
+        return {"student": self.state_dict(), "teacher": self.teacher_state_dict(), "momentum": self.flat_m.clone(),
+                "iter_num": self.iter_num, "lr": self.lr, "skipped_steps": self.skipped_steps}
+
+    def load_full_state(self, st):
+        self.model.load_state_dict(st["student"])
+        self.ema_model.load_state_dict(st["teacher"])
+        self.flat_m.copy_(st["momentum"])
+        self.iter_num, self.lr, self.skipped_steps = st["iter_num"], st["lr"], st["skipped_steps"]
+        for e in (self.s_eng, self.t_eng):
+            e.params_changed()
+        self.model.params_changed()
+        self.ema_model.params_changed()

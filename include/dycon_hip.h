@@ -1,0 +1,221 @@
+/* libdycon_hip.so -- C ABI of the MI355X-native DyCON training-step kernels.
+ *
+ * The reference (rogeliorjr/DyCON_Paper_Replication) has no FFI: its hot path is plain
+ * Python calling torch.nn / torch.nn.functional.  Each entry point below therefore cites the
+ * reference call site (file:line under code/) whose ATen/cuDNN work it replaces; the Python
+ * side (dycon_paper_replication_amd/) binds these with ctypes and mirrors the reference's
+ * callables (net_factory_3d, UnCLoss, FeCLoss, losses.*, ramps.*).  See INTEGRATION.md.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the name ends in _host;
+ *   - activations are channels-last-3D: (B, D, H, W, C) contiguous, C fastest ("NDHWC");
+ *   - dtype: DYCON_F32 or DYCON_BF16 storage; accumulation is always fp32;
+ *   - outputs and workspaces are caller-allocated, no hidden allocation, no host sync:
+ *     every call only enqueues work on `stream` and is hipGraph-capturable;
+ *   - return 0 on success, <0 on error; dycon_last_error() gives a thread-local message.
+ */
+#ifndef DYCON_HIP_H
+#define DYCON_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ihipStream_t* dycon_stream_t; /* == hipStream_t */
+
+#define DYCON_F32 0
+#define DYCON_BF16 1
+
+#define DYCON_OK 0
+#define DYCON_ERR_INVALID (-22)
+#define DYCON_ERR_LAUNCH (-5)
+
+/* gather modes of the convolution family */
+#define DYCON_CONV_1X1 0  /* nn.Conv3d(k=1)          VNet.py:175, UNet3D_contrastive.py:249-250,262,265 */
+#define DYCON_CONV_K3 1   /* nn.Conv3d(k=3, pad=1)   VNet.py:16, networks/utils.py:104,107              */
+#define DYCON_CONV_K2S2 2 /* nn.Conv3d(k=2, stride=2) VNet.py:73                                          */
+
+int dycon_version(void);
+const char* dycon_last_error(void);
+
+/* ---------------------------------------------------------------- weight packing
+ * Reorders one fp32 weight tensor (torch layout, arbitrary strides) into the MFMA B-fragment
+ * order consumed by dycon_conv_gemm:  K = T*Cin (tap-major, channel-minor), GEMM column
+ * n = n1*N0 + n0.  Element (t, c, n1, n0) is read from w[t'*s_t + c*s_c + n1*s_n1 + n0*s_n0]
+ * with t' = flip_taps ? T-1-t : t (flipped taps give the data-gradient of a k=3 conv).
+ * Output bytes: dycon_bfrag_bytes(). */
+size_t dycon_bfrag_bytes(int dtype, int T, int Cin, int N);
+int dycon_pack_bfrag(const float* w, void* out, int dtype, int T, int Cin, int N, int N0,
+                     long long s_t, long long s_c, long long s_n1, long long s_n0, int flip_taps,
+                     dycon_stream_t stream);
+/* plain fp32 [T][Cin][N] packing for the skinny (Cin<8 or N%16!=0) direct kernels */
+int dycon_pack_tcn(const float* w, float* out, int T, int Cin, int N, int N0, long long s_t,
+                   long long s_c, long long s_n1, long long s_n0, int flip_taps, dycon_stream_t stream);
+
+/* ---------------------------------------------------------------- convolution family (implicit GEMM on MFMA)
+ * y[row, n] (+)= bias[n % Cout] + sum_{t,c} x[src(row,t), c] * W[t, c, n]
+ *   rows  = voxels of the output grid (mode 1x1/k3: the input grid; k2s2: the half grid)
+ *   scatter=1: N = 8*Cout and column n = tap*Cout + co is written to output voxel
+ *              2*row+tap of the doubled grid  == nn.ConvTranspose3d(k=2, s=2)  (VNet.py:100)
+ *   accumulate=1: y += result (used to sum the two gradient paths into a skip tensor,
+ *              VNet.py:210-222 / networks/utils.py:276).
+ * Replaces F.conv3d / F.conv_transpose3d forward and their data-gradients.
+ * Needs Cin % 8 == 0 (bf16) or Cin % 4 == 0 (f32), N % 16 == 0; otherwise use *_direct. */
+int dycon_conv_gemm(const void* x, const void* wfrag, const float* bias, void* y, int dtype,
+                    int mode, int scatter, int accumulate, int B, int Di, int Hi, int Wi, int Cin,
+                    int N, int Cout, dycon_stream_t stream);
+/* skinny channels (first layer 1->16, 1x1 heads 16->2 and their data-gradient 2->16):
+ * w_tcn is fp32 [T][Cin][N]; x and y may have different dtypes (bf16 features, fp32 logits). */
+int dycon_conv_direct(const void* x, int x_dtype, const float* w_tcn, const float* bias, void* y,
+                      int y_dtype, int mode, int accumulate, int B, int Di, int Hi, int Wi, int Cin,
+                      int N, dycon_stream_t stream);
+
+/* weight gradient: dw[t*s_t + c*s_c + n*s_n] = sum_rows x[src(row,t), c] * gy[row, n]
+ * (x on the input grid with Cin channels, gy on the output-row grid with Cout channels).
+ * Two-stage, deterministic: per-split partials in `workspace`, then an ordered reduce. */
+size_t dycon_conv_wgrad_workspace(int mode, int B, int Di, int Hi, int Wi, int Cin, int Cout);
+int dycon_conv_wgrad(const void* x, int x_dtype, const void* gy, int g_dtype, float* dw, int mode,
+                     int B, int Di, int Hi, int Wi, int Cin, int Cout, long long s_t, long long s_c,
+                     long long s_n, float* workspace, size_t ws_bytes, dycon_stream_t stream);
+
+/* out[c] = sum_rows x[row, c]   (bias gradients; also per-channel sums) */
+size_t dycon_colsum_workspace(long long rows, int C);
+int dycon_colsum(const void* x, int dtype, float* out, long long rows, int C, float* workspace,
+                 size_t ws_bytes, dycon_stream_t stream);
+
+/* ---------------------------------------------------------------- normalisation (+ReLU, + skip add)
+ * One kernel family for nn.GroupNorm(16,C) (VNet.py:20), nn.InstanceNorm3d (G=C, no affine;
+ * networks/utils.py:105,108) and train-mode nn.BatchNorm3d (Nb=1, G=C over all B*V rows;
+ * UNet3D_contrastive.py:263,266).  x: (Nb, V, C).  stats: (Nb, G, 2) = {mean, rstd}. */
+size_t dycon_norm_workspace(int Nb, long long V, int C);
+int dycon_norm_stats(const void* x, int dtype, int Nb, long long V, int C, int G, float eps,
+                     float* stats, float* running_mean, float* running_var, float momentum,
+                     float* workspace, size_t ws_bytes, dycon_stream_t stream);
+/* y = act(gamma*(x-mean)*rstd + beta) + skip ; gamma/beta/skip may be NULL; y may alias x */
+int dycon_norm_apply(const void* x, void* y, int dtype, int Nb, long long V, int C, int G,
+                     const float* stats, const float* gamma, const float* beta, int relu,
+                     const void* skip, dycon_stream_t stream);
+/* backward.  src = x (from_y=0, xhat=(x-mean)*rstd) or, ONLY when relu=0 (the op is then
+ * invertible), y (from_y=1, xhat=(y-beta)/gamma).  gx may alias gy.  dgamma/dbeta may be NULL. */
+int dycon_norm_bwd(const void* src, int from_y, const void* gy, void* gx, int dtype, int Nb,
+                   long long V, int C, int G, const float* stats, const float* gamma,
+                   const float* beta, int relu, float* dgamma, float* dbeta, float* workspace,
+                   size_t ws_bytes, dycon_stream_t stream);
+
+/* ---------------------------------------------------------------- data movement / pointwise
+ * nn.MaxPool3d(2) (UNet3D_contrastive.py:225-237); idx holds the first-max position 0..7 */
+int dycon_maxpool2_fwd(const void* x, void* y, uint8_t* idx, int dtype, int B, int D, int H, int W,
+                       int C, dycon_stream_t stream);
+int dycon_maxpool2_bwd(const void* gy, const uint8_t* idx, void* gx, int dtype, int B, int D, int H,
+                       int W, int C, dycon_stream_t stream);
+/* trilinear resize (networks/utils.py:264 align_corners=False; UNet3D_contrastive.py:309 True).
+ * y/gy rows have `ldy` channels per voxel and the op touches channels [coff, coff+C): this is how
+ * the decoder's torch.cat([skip, up]) (networks/utils.py:276) is written without a copy pass. */
+int dycon_trilinear_fwd(const void* x, void* y, int dtype, int B, int Di, int Hi, int Wi, int Do,
+                        int Ho, int Wo, int C, int ldy, int coff, int align_corners,
+                        dycon_stream_t stream);
+int dycon_trilinear_bwd(const void* gy, void* gx, int dtype, int B, int Di, int Hi, int Wi, int Do,
+                        int Ho, int Wo, int C, int ldy, int coff, int align_corners,
+                        dycon_stream_t stream);
+/* dst[row, doff + c] = src[row, soff + c]  (concat / split of channel slices) */
+int dycon_copy_channels(const void* src, int lds, int soff, void* dst, int ldd, int doff,
+                        long long rows, int C, int dtype, dycon_stream_t stream);
+/* y[b, v, c] = x[b, v, c] * scale[b, c]   (nn.Dropout3d(0.5), VNet.py:177,196,226; fwd and bwd) */
+int dycon_scale_channels(const void* x, const float* scale, void* y, int dtype, int B, long long V,
+                         int C, dycon_stream_t stream);
+/* y = x * mask * inv_keep  with an explicit float keep-mask (parity tests) */
+int dycon_mul_mask(const void* x, const float* mask, float inv_keep, void* y, int dtype,
+                   long long n, dycon_stream_t stream);
+/* Philox4x32-10 element-wise dropout (nn.Dropout(0.3), UNet3D_contrastive.py:253-254):
+ * keep = u > p ; the same (seed, offset) regenerates the mask in backward */
+int dycon_dropout_philox(const void* x, void* y, int dtype, long long n, float p, uint64_t seed,
+                         uint64_t offset, dycon_stream_t stream);
+/* scale[i] = bernoulli(1-p)/(1-p)  for i < n   (channel masks of Dropout3d) */
+int dycon_channel_mask_philox(float* scale, long long n, float p, uint64_t seed, uint64_t offset,
+                              dycon_stream_t stream);
+/* y = x + clamp(N(0,1)*sigma, -clip, clip)   (train_DyCON_BraTS19.py:301-302); noise==NULL:
+ * Philox + Box-Muller, else the explicit noise tensor is added (parity tests) */
+int dycon_add_noise(const void* x, const float* noise, void* y, int dtype, long long n, float sigma,
+                    float clip, uint64_t seed, uint64_t offset, dycon_stream_t stream);
+int dycon_tanh(const void* x, int x_dtype, float* y, long long n, dycon_stream_t stream);
+int dycon_cast(const void* x, int x_dtype, void* y, int y_dtype, long long n, dycon_stream_t stream);
+/* y = a + b (b may be NULL -> copy) */
+int dycon_add(const void* a, const void* b, void* y, int dtype, long long n, dycon_stream_t stream);
+
+/* ---------------------------------------------------------------- voxel losses (2 classes)
+ * One pass over student+teacher logits (fp32, (B,V,2)) and labels accumulates every sum the
+ * step needs (train_DyCON_BraTS19.py:308-314,351-352; utils/losses.py:8-16,65-104,156-192;
+ * utils/dycon_losses.py:94-118) into sums[16] (double, zeroed by the call):
+ *   0 ce_sum   1 I1  2 Z1  3 Y1   4 I0  5 Z0  6 Y0   7 mse_sum  8 kl_sum  9 uncl_w  10 uncl_h
+ * samples [0,LB) are labelled (CE, Dice), [LB,B) feed the consistency term, all feed UnCL. */
+int dycon_seg_losses_fwd(const float* s_logits, const float* t_logits, const void* labels,
+                         int label_bytes, int B, int LB, long long V, float beta, double* sums,
+                         dycon_stream_t stream);
+/* g_logits = sum_k coef[k] * d(loss_k)/d(s_logits); coef (device, 5 floats): ce, dice_fg,
+ * dice_multiclass, consistency (mse or kl per cons_kind), uncl -- already multiplied by the
+ * upstream gradient.  Needs the sums from the forward call. */
+int dycon_seg_losses_bwd(const float* s_logits, const float* t_logits, const void* labels,
+                         int label_bytes, int B, int LB, long long V, float beta, const double* sums,
+                         const float* coef, int cons_kind, float* g_logits, dycon_stream_t stream);
+
+/* vals[6] (device floats) = ce, dice(class 1), dice(mean over classes), cons mse, cons kl, uncl */
+int dycon_seg_losses_finalize(const double* sums, int B, int LB, long long V, float beta, float* vals,
+                              dycon_stream_t stream);
+/* out[6] = total, ce, dice, cons, fecl, uncl with total = l_w*(ce+dice) + cons_w*cons + u_w*(fecl+uncl)
+ * (train_DyCON_BraTS19.py:355-357); nonfinite[0] = !isfinite(total) (the NaN/Inf guard, :360-362).
+ * dice_kind 0: class-1 dice, 1: multi-class; cons_kind 0: mse, 1: kl; fecl may be NULL. */
+int dycon_step_loss(const float* vals, const float* fecl, float l_weight, float cons_weight,
+                    float u_weight, int dice_kind, int cons_kind, float* out, int* nonfinite,
+                    dycon_stream_t stream);
+
+/* rows of (R, C): y = x / max(||x||, eps)   (F.normalize, train_DyCON_BraTS19.py:316-323) */
+int dycon_l2norm_fwd(const void* x, void* y, float* norms, int dtype, long long R, int C, float eps,
+                     dycon_stream_t stream);
+int dycon_l2norm_bwd(const void* y, const float* norms, const void* gy, void* gx, int dtype,
+                     long long R, int C, float eps, dycon_stream_t stream);
+/* mask[b, n] = avg_pool3d(label, k) > 0.5   (train_DyCON_BraTS19.py:326-330) */
+int dycon_mask_pool(const void* labels, int label_bytes, float* mask, int B, int D, int H, int W,
+                    int kd, int kh, int kw, dycon_stream_t stream);
+
+/* ---------------------------------------------------------------- FeCL (utils/dycon_losses.py:150-235)
+ * Blockwise: the (B,N,N) similarity matrix is never materialised; Gram tiles are recomputed on
+ * MFMA in each of the passes.  feat/teacher: (B,N,Dm) L2-normalised rows; mask: (B,N) float.
+ * out (device, 4 doubles, zeroed by the call): student_sum, cross_num, cross_cnt, unused.
+ * loss[0] (device float) = student_sum/(B*N) + lambda_cross*cross_num/(cross_cnt+1e-18). */
+size_t dycon_fecl_workspace(int B, int N);
+int dycon_fecl_fwd(const void* feat, const void* teacher, const float* mask, const float* gambling,
+                   int dtype, int B, int N, int Dm, float temperature, float gamma, int use_focal,
+                   float cross_thresh, float lambda_cross, double* out, float* loss, float* workspace,
+                   size_t ws_bytes, dycon_stream_t stream);
+/* recompute loss[0] from `out` (after the sums were all-reduced across ranks); rows = global B*N */
+int dycon_fecl_finalize(const double* out, double rows, float lambda_cross, int has_teacher, float* loss,
+                        dycon_stream_t stream);
+/* g_feat = coef[0] * d(loss)/d(feat); needs workspace and `out` untouched since the forward */
+int dycon_fecl_bwd(const void* feat, const void* teacher, const float* mask, const float* gambling,
+                   int dtype, int B, int N, int Dm, float temperature, float gamma, int use_focal,
+                   float cross_thresh, float lambda_cross, const double* out, const float* coef,
+                   void* g_feat, float* workspace, size_t ws_bytes, dycon_stream_t stream);
+
+/* ---------------------------------------------------------------- optimiser (train_DyCON_BraTS19.py:155-164,268,369-372)
+ * sumsq[0] += sum g^2 (double, caller zeroes) -> clip_grad_norm_; then one fused pass:
+ *   coef = min(1, max_norm/(sqrt(sumsq)+1e-6)); g = coef*g + wd*p; m = mu*m + g; p -= lr*m   on [0,n_sgd)
+ *   teacher = alpha*teacher + (1-alpha)*p                                                    on [0,n_all)
+ * skip_flag (device int, may be NULL): non-zero -> leave everything untouched (NaN/Inf loss). */
+int dycon_sumsq(const float* g, long long n, double* sumsq, dycon_stream_t stream);
+int dycon_sgd_ema(float* p, const float* g, float* mom, float* teacher, long long n_sgd,
+                  long long n_all, const double* sumsq, float max_norm, float grad_scale, float lr,
+                  float momentum, float weight_decay, float ema_alpha, const int* skip_flag,
+                  dycon_stream_t stream);
+/* dst[i] = v_i for i < n <= 8: host scalars (loss weights) into device memory without a copy engine round trip */
+int dycon_set_scalars(float* dst, int n, float v0, float v1, float v2, float v3, float v4, float v5,
+                      float v6, float v7, dycon_stream_t stream);
+/* flag[0] = !isfinite(x[0]) */
+int dycon_nonfinite_flag(const float* x, int* flag, dycon_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DYCON_HIP_H */

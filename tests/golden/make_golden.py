@@ -386,7 +386,9 @@ def gen_full_nets():
     r3 = rng_t(rng, *ulog.shape)
     r4 = rng_t(rng, *ufeat.shape)
     unames = [k for k, _ in unet.named_parameters()]
-    ugr = torch.autograd.grad((ulog * r3).sum() + (ufeat * r4).sum() + sdf.sum(), list(unet.parameters()), allow_unused=True)
+    # the sdf head (tanh(final(up1))) is discarded by the training step, so it is left out of the objective:
+    # final.* get no gradient (None -> zero statistics), exactly as in train_DyCON_BraTS19.py:304
+    ugr = torch.autograd.grad((ulog * r3).sum() + (ufeat * r4).sum(), list(unet.parameters()), allow_unused=True)
     out.update({"unet.logits_sub": _sub(ulog), "unet.logits_stats": stats(ulog), "unet.sdf_stats": stats(sdf),
                 "unet.feats": ufeat, "unet.param_seed": np.array(12)})
     out["unet.grad_stats"] = np.stack([stats(g) for g in ugr])

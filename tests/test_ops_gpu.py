@@ -1,0 +1,374 @@
+"""GPU parity tests, op level: every HIP kernel (called through the C ABI) against the oracle /
+the golden fixtures from the reference.  fp32 storage: tolerance 1e-4 (north-star); bf16: loose.
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+if torch.cuda.is_available():
+    from dycon_paper_replication_amd import ops
+    from dycon_paper_replication_amd.engine import Engine
+from oracle import losses as OL
+from oracle import step as OS
+
+DEV = "cuda:0"
+T = torch.from_numpy
+
+
+def nd(t, dtype=torch.float32):
+    """NCDHW cpu -> NDHWC cuda"""
+    return t.permute(0, 2, 3, 4, 1).contiguous().to(DEV, dtype)
+
+
+def nc(t):
+    """NDHWC cuda -> NCDHW cpu fp32"""
+    return t.float().cpu().permute(0, 4, 1, 2, 3).contiguous()
+
+
+def close(a, b, rtol=1e-4, atol=1e-5, msg=""):
+    a = a.detach().float().cpu().numpy() if torch.is_tensor(a) else np.asarray(a)
+    b = b.detach().float().cpu().numpy() if torch.is_tensor(b) else np.asarray(b)
+    np.testing.assert_allclose(a, b, rtol=rtol, atol=atol, err_msg=msg)
+
+
+def relclose(a, b, tol, msg=""):
+    """max |a-b| <= tol * max|b|  (for bf16 comparisons)"""
+    a = a.detach().float().cpu()
+    b = b.detach().float().cpu()
+    err = (a - b).abs().max().item()
+    ref = b.abs().max().item() + 1e-12
+    assert err <= tol * ref, f"{msg}: max err {err:.3e} vs scale {ref:.3e}"
+
+
+def mini_engine(params, dtype=torch.float32):
+    p = {k: v.to(DEV).contiguous() for k, v in params.items()}
+    g = {k: torch.full_like(v, float("nan")) for k, v in p.items()}
+    e = Engine("vnet", p, g, {}, dtype=dtype)
+    e.recording, e.update_bn = True, True
+    e.tape, e.G = [], {}
+    from dycon_paper_replication_amd.engine import DropoutSpec
+    e.dropout = DropoutSpec("off")
+    return e
+
+
+CONV_CASES = [
+    # kind, cin, cout, spatial(in)
+    ("k3", 16, 32, (6, 8, 10)), ("k3", 32, 16, (5, 7, 9)), ("k3", 64, 64, (4, 4, 6)), ("k3", 48, 16, (4, 6, 5)),
+    ("k2s2", 16, 32, (8, 6, 10)), ("k2s2", 64, 128, (4, 4, 2)),
+    ("deconv", 32, 16, (4, 3, 5)), ("deconv", 128, 64, (2, 3, 2)),
+    ("1x1", 256, 512, (2, 3, 2)), ("1x1", 16, 2, (4, 6, 8)), ("k3", 1, 16, (8, 8, 12)),
+]
+
+
+@pytest.mark.parametrize("kind,cin,cout,sp", CONV_CASES)
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_conv(kind, cin, cout, sp, dtype):
+    rng = np.random.default_rng(hash((kind, cin, cout)) % 2**31)
+    B = 2
+    k = {"k3": 3, "k2s2": 2, "deconv": 2, "1x1": 1}[kind]
+    wshape = (cin, cout, k, k, k) if kind == "deconv" else (cout, cin, k, k, k)
+    w = T((rng.standard_normal(wshape) / np.sqrt(cin * k ** 3)).astype(np.float32))
+    b = T(rng.standard_normal(cout).astype(np.float32))
+    x = T(rng.standard_normal((B, cin) + sp).astype(np.float32))
+    if dtype == torch.bfloat16:   # compare against the oracle on the same bf16-rounded inputs
+        x = x.bfloat16().float()
+    xr = x.clone().requires_grad_(True)
+    wr = w.clone().requires_grad_(True)
+    br = b.clone().requires_grad_(True)
+    wq = wr.bfloat16().float() if dtype == torch.bfloat16 else wr
+    if kind == "k3":
+        yr = F.conv3d(xr, wq, br, padding=1)
+    elif kind == "k2s2":
+        yr = F.conv3d(xr, wq, br, stride=2)
+    elif kind == "deconv":
+        yr = F.conv_transpose3d(xr, wq, br, stride=2)
+    else:
+        yr = F.conv3d(xr, wq, br)
+    gy = T(rng.standard_normal(tuple(yr.shape)).astype(np.float32))
+    out_f32 = (kind == "1x1" and cout == 2)
+    if dtype == torch.bfloat16 and not out_f32:
+        gy = gy.bfloat16().float()
+    yr.backward(gy)
+
+    e = mini_engine({"l.weight": w, "l.bias": b}, dtype)
+    xd = nd(x, dtype)
+    y = e._conv("l", xd, kind, need_gx=cin > 1, out_dtype=torch.float32 if out_f32 else None)
+    e.G[id(y)] = nd(gy, y.dtype)
+    for fn in reversed(e.tape):
+        fn()
+    torch.cuda.synchronize()
+    if dtype == torch.float32:
+        close(nc(y), yr, 1e-4, 1e-5, "y")
+        close(e.g["l.weight"], wr.grad, 1e-4, 2e-4, "gw")
+        close(e.g["l.bias"], br.grad, 1e-4, 2e-4, "gb")
+        if cin > 1:
+            close(nc(e.G[id(xd)]), xr.grad, 1e-4, 1e-5, "gx")
+    else:
+        relclose(nc(y), yr, 1e-2, "y")
+        relclose(e.g["l.weight"], wr.grad, 1e-2, "gw")
+        relclose(e.g["l.bias"], br.grad, 1e-2, "gb")
+        if cin > 1:
+            relclose(nc(e.G[id(xd)]), xr.grad, 1e-2, "gx")
+
+
+def test_conv_accumulate():
+    """data-gradient accumulation into an existing buffer (skip connections)"""
+    rng = np.random.default_rng(5)
+    w = T((rng.standard_normal((32, 16, 2, 2, 2)) * 0.1).astype(np.float32))
+    b = torch.zeros(32)
+    x = T(rng.standard_normal((1, 16, 4, 4, 6)).astype(np.float32))
+    e = mini_engine({"l.weight": w, "l.bias": b})
+    xd = nd(x)
+    y = e._conv("l", xd, "k2s2")
+    gy = torch.randn(y.shape, device=DEV)
+    prior = torch.randn(xd.shape, device=DEV)
+    e.G[id(y)] = gy
+    e.G[id(xd)] = prior.clone()
+    for fn in reversed(e.tape):
+        fn()
+    xr = x.clone().requires_grad_(True)
+    F.conv3d(xr, w, b, stride=2).backward(nc(gy))
+    close(nc(e.G[id(xd)]), xr.grad + nc(prior), 1e-4, 1e-5)
+
+
+@pytest.mark.parametrize("kind,C", [("gn", 32), ("gn", 16), ("in", 16), ("in", 48), ("bn", 512)])
+@pytest.mark.parametrize("mode", ["relu", "skip", "norelu"])
+def test_norm(kind, C, mode):
+    rng = np.random.default_rng(C)
+    B, sp = 2, (4, 6, 5)
+    z = T((rng.standard_normal((B, C) + sp) * 1.5 + 0.3).astype(np.float32))
+    gamma = T((1 + 0.2 * rng.standard_normal(C)).astype(np.float32))
+    beta = T((0.2 * rng.standard_normal(C)).astype(np.float32))
+    skip = T(rng.standard_normal((B, C) + sp).astype(np.float32))
+    relu = mode != "norelu"
+    zr = z.clone().requires_grad_(True)
+    gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    if kind == "gn":
+        yr = F.group_norm(zr, 16, gr, br, 1e-5)
+    elif kind == "in":
+        yr = F.instance_norm(zr, eps=1e-5)
+    else:
+        yr = F.batch_norm(zr, None, None, gr, br, True, 0.1, 1e-5)
+    if relu:
+        yr = F.relu(yr)
+    if mode == "skip":
+        yr = yr + skip
+    gy = T(rng.standard_normal(tuple(yr.shape)).astype(np.float32))
+    yr.backward(gy)
+    params = {"n.weight": gamma, "n.bias": beta} if kind != "in" else {}
+    e = mini_engine(params)
+    zd = nd(z)
+    sd = nd(skip) if mode == "skip" else None
+    y = e._norm("n" if kind != "in" else None, zd, kind, relu=relu, skip=sd)
+    ycopy = y.clone()
+    e.G[id(y)] = nd(gy)
+    for fn in reversed(e.tape):
+        fn()
+    close(nc(ycopy), yr, 1e-4, 2e-5, "y")
+    close(nc(e.G[id(zd)]), zr.grad, 2e-4, 2e-5, "gz")
+    if kind != "in":
+        close(e.g["n.weight"], gr.grad, 2e-4, 2e-4, "dgamma")
+        close(e.g["n.bias"], br.grad, 2e-4, 2e-4, "dbeta")
+    if mode == "skip":
+        close(nc(e.G[id(sd)]), gy, 0, 0, "gskip")
+    if mode == "norelu" and kind != "in":
+        # without ReLU the op is invertible: the backward may recover xhat from y (from_y = 1)
+        Nb, G, V = (1, C, B * 120) if kind == "bn" else (B, 16, 120)
+        stats = ops.norm_stats(zd, Nb, V, C, G)
+        gz2 = ops.norm_bwd(ycopy, True, nd(gy), stats, Nb, V, C, G, e.p["n.weight"], e.p["n.bias"], False)
+        close(nc(gz2), zr.grad, 2e-3, 2e-4, "gz from y")
+
+
+def test_golden_pool_trilinear():
+    g = load_golden("unet_layers")
+    x = T(g["maxpool.x"])
+    y, idx = ops.maxpool2_fwd(nd(x))
+    close(nc(y), g["maxpool.y"], 0, 0)
+    gx = ops.maxpool2_bwd(nd(T(g["maxpool.r"])), idx, nd(x).shape)
+    close(nc(gx), g["maxpool.gx"], 0, 0)
+    x = T(g["tri.x"])
+    xd = nd(x)
+    for tag, scale, align in (("up2", 2, False), ("head2", 2, True), ("head4", 4, True)):
+        out = tuple(s * scale for s in x.shape[2:])
+        y = ops.trilinear_fwd(xd, out, align)
+        close(nc(y), g[f"tri_{tag}.y"], 1e-5, 1e-6, tag)
+        gx = ops.trilinear_bwd(nd(T(g[f"tri_{tag}.r"])), xd.shape, align)
+        close(nc(gx), g[f"tri_{tag}.gx"], 1e-4, 1e-5, tag + " bwd")
+    # channel-window variant (concat without a copy)
+    cat = torch.zeros((1, 6, 10, 8, 7), device=DEV)
+    ops.trilinear_fwd(xd, (6, 10, 8), False, out=cat, coff=2)
+    close(nc(cat[..., 2:5].contiguous()), g["tri_up2.y"], 1e-5, 1e-6)
+    assert float(cat[..., :2].abs().max()) == 0 and float(cat[..., 5:].abs().max()) == 0
+
+
+def test_pointwise():
+    x = torch.randn(2, 4, 5, 6, 16, device=DEV)
+    scale = torch.rand(2 * 16, device=DEV)
+    close(ops.scale_channels(x, scale), x * scale.view(2, 1, 1, 1, 16), 1e-6, 1e-7)
+    dst = torch.zeros(2, 4, 5, 6, 40, device=DEV)
+    ops.copy_channels(x, 4, dst, 10, 8)
+    close(dst[..., 10:18], x[..., 4:12], 0, 0)
+    assert float(dst[..., :10].abs().max()) == 0
+    close(ops.add(x, x), 2 * x, 0, 0)
+    close(ops.tanh(x), torch.tanh(x), 1e-5, 1e-6)
+    close(ops.cast(ops.cast(x, torch.bfloat16), torch.float32), x.bfloat16().float(), 0, 0)
+    mask = (torch.rand_like(x) > 0.3).float()
+    close(ops.mul_mask(x, mask, 1 / 0.7), x * mask / 0.7, 1e-6, 1e-7)
+    # Philox dropout: keep-rate, scaling and reproducibility
+    big = torch.ones(1 << 20, device=DEV)
+    y1 = ops.dropout_philox(big, 0.3, 1234, 77)
+    y2 = ops.dropout_philox(big, 0.3, 1234, 77)
+    assert torch.equal(y1, y2)
+    keep = (y1 != 0).float().mean().item()
+    assert abs(keep - 0.7) < 5e-3
+    close(y1[y1 != 0], torch.full_like(y1[y1 != 0], 1 / 0.7), 1e-6, 0)
+    assert not torch.equal(y1, ops.dropout_philox(big, 0.3, 1234, 78 + (1 << 20)))
+    cm = ops.channel_mask_philox(4096, 0.5, 9, 0, DEV)
+    assert abs((cm != 0).float().mean().item() - 0.5) < 0.05 and set(cm.unique().tolist()) <= {0.0, 2.0}
+    # teacher noise: clamp(N(0,1)*0.1, +-0.2)
+    z = torch.zeros(1 << 20, device=DEV)
+    n = ops.add_noise(z, None, 0.1, 0.2, 42, 0)
+    assert float(n.abs().max()) <= 0.2 + 1e-7
+    assert abs(float(n.mean())) < 1e-3 and abs(float(n.std()) - 0.0954) < 2e-3     # std of N(0,.1) clamped at 2 sigma
+    assert float((n.abs() >= 0.2 - 1e-7).float().mean()) == pytest.approx(0.0455, abs=3e-3)
+    ex = torch.randn(1000, device=DEV)
+    close(ops.add_noise(torch.ones(1000, device=DEV), ex), 1 + ex, 1e-6, 1e-7)
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_uncl_golden(tag):
+    g = load_golden(f"uncl_{tag}")
+    s, t = nd(T(g["s"])), nd(T(g["t"]))
+    B = s.shape[0]
+    V = s.numel() // (2 * B)
+    lab = torch.zeros(s.shape[:4], dtype=torch.uint8, device=DEV)
+    for i, beta in enumerate(g["betas"]):
+        sums = ops.seg_losses_fwd(s, t, lab, 0, float(beta))
+        vals = ops.seg_losses_finalize(sums, B, 0, V, float(beta))
+        close(vals[5], g[f"loss{i}"], 1e-5, 1e-6)
+        coef = torch.tensor([0, 0, 0, 0, 1.0], device=DEV)
+        gs = ops.seg_losses_bwd(s, t, lab, 0, float(beta), sums, coef)
+        close(nc(gs), g[f"grad{i}"], 1e-4, 1e-8)
+
+
+def test_voxel_losses_golden():
+    g = load_golden("voxel_losses")
+    a, b, lab = T(g["a"]), T(g["b"]), T(g["label"])
+    B = a.shape[0]
+    V = a.numel() // (2 * B)
+    ad, labd = nd(a), lab.to(DEV)
+    # labelled terms: every sample labelled (LB = B)
+    sums = ops.seg_losses_fwd(ad, nd(b), labd, B, 1.0)
+    vals = ops.seg_losses_finalize(sums, B, B, V, 1.0)
+    close(vals[0], g["ce"], 1e-5, 1e-6)
+    close(vals[1], g["dice"], 1e-5, 1e-6)
+    close(vals[2], g["dice_mc"], 1e-5, 1e-6)
+    for k, key in ((0, "ce_grad"), (1, "dice_grad"), (2, "dice_mc_grad")):
+        coef = torch.zeros(5, device=DEV)
+        coef[k] = 1
+        close(nc(ops.seg_losses_bwd(ad, nd(b), labd, B, 1.0, sums, coef)), g[key], 1e-4, 1e-8, key)
+    # consistency terms: no sample labelled (LB = 0); uint8 labels exercise the other label path
+    sums = ops.seg_losses_fwd(ad, nd(b), labd.to(torch.uint8), 0, 1.0)
+    vals = ops.seg_losses_finalize(sums, B, 0, V, 1.0)
+    close(vals[3], g["cons_mse"], 1e-5, 1e-7)
+    close(vals[4], g["cons_kl"], 1e-4, 1e-7)
+    coef = torch.tensor([0, 0, 0, 1.0, 0], device=DEV)
+    close(nc(ops.seg_losses_bwd(ad, nd(b), labd.to(torch.uint8), 0, 1.0, sums, coef, 0)), g["cons_mse_grad"], 1e-4, 1e-9)
+    close(nc(ops.seg_losses_bwd(ad, nd(b), labd.to(torch.uint8), 0, 1.0, sums, coef, 1)), g["cons_kl_grad"], 1e-4, 1e-9)
+
+
+@pytest.mark.parametrize("tag", ["small", "mid", "oneclass", "singleton", "ragged"])
+def test_fecl_golden(tag):
+    """FeCL against the REFERENCE's own outputs (loss and gradient), all ramp epochs / focal / teacher / gambling."""
+    g = load_golden(f"fecl_{tag}")
+    feat, teach = T(g["feat"]).to(DEV), T(g["teacher"]).to(DEV)
+    mask = T(g["mask"]).reshape(feat.shape[0], -1).contiguous().to(DEV)
+    gamb = T(g["gambling"]).contiguous().to(DEV)
+    for i in range(int(g["n_cfg"])):
+        epoch, focal, use_t, use_g = [int(v) for v in g[f"cfg{i}"]]
+        thr = OL.threshold_rampup(epoch, 1500, 0.3, 0.5)
+        args = (feat, teach if use_t else None, mask, gamb if use_g else None, 0.6, 2.0, bool(focal), thr, 1.0)
+        loss, st = ops.fecl_fwd(*args)
+        close(loss[0], g[f"loss{i}"], 1e-4, 1e-6, f"loss cfg{i}")
+        coef = torch.ones(1, device=DEV)
+        gf = ops.fecl_bwd(*args, st, coef)
+        ref = g[f"grad{i}"]
+        scale = np.abs(ref).max() + 1e-12
+        err = np.abs(gf.cpu().numpy() - ref).max()
+        assert err <= 1e-4 * scale + 1e-8, f"grad cfg{i}: {err} vs {scale}"
+
+
+def test_fecl_bf16_and_full_size():
+    """N = 1728, Dm = 256 (config 2) in bf16 storage vs the fp32 oracle on the rounded inputs."""
+    torch.manual_seed(3)
+    B, N, Dm = 2, 1728, 256
+    f = F.normalize(torch.randn(B, N, Dm), dim=-1).bfloat16()
+    t = F.normalize(f.float() + 0.02 * torch.randn(B, N, Dm), dim=-1).bfloat16()
+    mask = (torch.rand(B, N) > 0.8).float()
+    thr = 0.35
+    fr = f.float().requires_grad_(True)
+    ref = OL.fecl(fr, mask.view(B, 1, N), t.float(), None, 300, 0.6, 2.0, True, 1500, 1.0)
+    assert OL.threshold_rampup(300, 1500, 0.3, 0.5) == pytest.approx(0.3 + 0.2 * np.exp(-5 * 0.64))
+    thr = OL.threshold_rampup(300, 1500, 0.3, 0.5)
+    (gr,) = torch.autograd.grad(ref, fr)
+    args = (f.to(DEV), t.to(DEV), mask.to(DEV), None, 0.6, 2.0, True, thr, 1.0)
+    loss, st = ops.fecl_fwd(*args)
+    close(loss[0], ref, 2e-4, 1e-6)
+    gf = ops.fecl_bwd(*args, st, torch.ones(1, device=DEV))
+    relclose(gf, gr, 2e-2, "fecl bf16 grad")
+
+
+def test_l2norm_maskpool():
+    x = torch.randn(3, 50, 256)
+    x[0, 3] = 0          # below the eps clamp
+    xr = x.clone().requires_grad_(True)
+    yr = F.normalize(xr, dim=-1)
+    gy = torch.randn_like(x)
+    yr.backward(gy)
+    y, nrm = ops.l2norm_fwd(x.to(DEV))
+    close(y, yr, 1e-5, 1e-6)
+    close(ops.l2norm_bwd(y, nrm, gy.to(DEV)), xr.grad, 1e-4, 1e-5)
+    lab = (torch.rand(2, 16, 24, 8) > 0.5).long()
+    close(ops.mask_pool(lab.to(DEV), 8), OL.contrast_mask(lab, 8).reshape(2, -1), 0, 0)
+    close(ops.mask_pool(lab.to(DEV).to(torch.uint8), (4, 8, 2)),
+          (F.avg_pool3d(lab.float().unsqueeze(1), (4, 8, 2)) > 0.5).float().reshape(2, -1), 0, 0)
+
+
+def test_optimizer():
+    rng = np.random.default_rng(9)
+    n, n_sgd = 1000, 900
+    p = T(rng.standard_normal(n).astype(np.float32))
+    teacher = T(rng.standard_normal(n).astype(np.float32))
+    ps, ts, mom = {"a": p[:n_sgd].clone()}, {"a": teacher.clone()}, {}
+    pd, td = p.to(DEV), teacher.to(DEV)
+    md = torch.zeros(n, device=DEV)
+    full = p.clone()
+    for step in range(3):
+        g = T((rng.standard_normal(n) * (3.0 if step == 0 else 0.01)).astype(np.float32))
+        gn, gc = OS.clip_grad_norm({"a": g[:n_sgd]}, 1.0)
+        OS.sgd_step(ps, gc, mom, 0.01, 0.9, 1e-4)
+        full = torch.cat([ps["a"], full[n_sgd:]])
+        t_all = {"a": ts["a"]}
+        OS.ema_update(t_all, {"a": full}, 0.99, step)
+        ts = t_all
+        ss = torch.zeros(1, dtype=torch.float64, device=DEV)
+        gd = g.to(DEV)
+        ops.sumsq(gd[:n_sgd].contiguous(), ss)
+        close(ss.sqrt(), gn, 1e-5, 0)
+        alpha = min(1 - 1 / (step + 1), 0.99)
+        ops.sgd_ema(pd, gd, md, td, n_sgd, ss, 1.0, 1.0, 0.01, 0.9, 1e-4, alpha)
+        close(pd, full, 1e-5, 1e-6, f"params step {step}")
+        close(td, ts["a"], 1e-5, 1e-6, f"teacher step {step}")
+    # skip flag: nothing moves
+    flag = torch.ones(1, dtype=torch.int32, device=DEV)
+    before = pd.clone()
+    ops.sgd_ema(pd, gd, md, td, n_sgd, ss, 1.0, 1.0, 0.01, 0.9, 1e-4, 0.99, flag)
+    assert torch.equal(before, pd)
+    f2 = torch.zeros(1, dtype=torch.int32, device=DEV)
+    ops.nonfinite_flag(torch.tensor([float("nan")], device=DEV), f2)
+    assert int(f2) == 1

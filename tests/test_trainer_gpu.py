@@ -1,0 +1,105 @@
+"""GPU parity, step level: DyconTrainer (HIP path, fp32 storage) against the 2-step traces recorded
+from the REFERENCE modules/losses/optimizer (tests/golden/step_{unet,vnet}.npz)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+if torch.cuda.is_available():
+    from dycon_paper_replication_amd.engine import DropoutSpec
+    from dycon_paper_replication_amd.trainer import DyconTrainer, TrainConfig
+from oracle import nets as ON
+from oracle import step as OS
+
+DEV = "cuda:0"
+T = torch.from_numpy
+
+
+def _stats(t):
+    t = t.detach().double().cpu()
+    return np.array([t.sum().item(), t.abs().sum().item(), (t * t).sum().item()])
+
+
+@pytest.mark.parametrize("kind", ["unet", "vnet"])
+def test_two_step_trace_vs_reference(kind):
+    g = load_golden(f"step_{kind}")
+    net_type = "unet_3D" if kind == "unet" else "vnet"
+    mk = ON.make_unet_params if kind == "unet" else ON.make_vnet_params
+    s0, s1 = [int(v) for v in g["seeds"]]
+    cfg = TrainConfig(model=net_type, labeled_bs=int(g["LB"]), batch_size=int(g["B"]), dtype=torch.float32, feature_scaler=2)
+    tr = DyconTrainer(cfg, DEV, student_init=mk(s0), teacher_init=mk(s1))
+    names = list(g["param_names"])
+    assert names == tr.names
+    off = DropoutSpec("off")
+    for step in range(2):
+        vol = T(g[f"s{step}.vol"]).to(DEV)
+        lab = T(g[f"s{step}.label"]).to(DEV)            # uint8 labels
+        noise = T(g[f"s{step}.noise"]).to(DEV)
+        out = tr.step(vol, lab, noise=noise, s_drop=off, t_drop=off, epoch=int(g[f"s{step}.epoch"]), beta=float(g[f"s{step}.beta"]))
+        ref = g[f"s{step}.scalars"]   # loss, ce, dice, cons, fecl, uncl, cons_weight, grad_norm
+        got = [float(out[k]) for k in ("loss", "ce", "dice", "cons", "fecl", "uncl")] + [out["cons_weight"], float(out["grad_sumsq"].sqrt())]
+        np.testing.assert_allclose(got, ref, rtol=1e-4, atol=1e-6, err_msg=f"scalars step {step}")
+        lo = out["s_logits"].cpu().permute(0, 4, 1, 2, 3)[..., ::2, ::2, ::2]
+        np.testing.assert_allclose(lo.numpy(), g[f"s{step}.logits_sub"], rtol=1e-4, atol=1e-4)
+        tl = out["t_logits"].cpu().permute(0, 4, 1, 2, 3)[..., ::2, ::2, ::2]
+        np.testing.assert_allclose(tl.numpy(), g[f"s{step}.t_logits_sub"], rtol=1e-4, atol=1e-4)
+        np.testing.assert_array_equal(out["mask"].cpu().numpy().reshape(g[f"s{step}.mask"].shape), g[f"s{step}.mask"])
+        for k, ref_s, ref_t in zip(names, g[f"s{step}.student_stats"], g[f"s{step}.teacher_stats"]):
+            np.testing.assert_allclose(_stats(tr.p[k]), ref_s, rtol=1e-4, atol=1e-4, err_msg=f"student {k} step {step}")
+            np.testing.assert_allclose(_stats(tr.t[k]), ref_t, rtol=1e-4, atol=1e-4, err_msg=f"teacher {k} step {step}")
+    assert tr.iter_num == 2 and tr.skipped_steps == 0
+    # state_dict contract: reference keys, shapes; loadable into the oracle's functional net
+    sd = tr.state_dict()
+    ref_sd = mk(s0)
+    assert list(sd) == list(ref_sd)
+    assert all(tuple(sd[k].shape) == tuple(ref_sd[k].shape) for k in sd)
+
+
+def test_nan_guard_skips_update():
+    cfg = TrainConfig(model="vnet", labeled_bs=1, batch_size=2, dtype=torch.float32)
+    tr = DyconTrainer(cfg, DEV)
+    vol = torch.randn(2, 1, 16, 16, 16, device=DEV)
+    vol[0, 0, 0, 0, 0] = float("nan")
+    lab = torch.zeros(2, 16, 16, 16, dtype=torch.int64, device=DEV)
+    before = tr.flat_p.clone()
+    tb = tr.flat_t.clone()
+    out = tr.step(vol, lab)
+    assert out["skipped"] and tr.iter_num == 0 and tr.skipped_steps == 1
+    assert torch.equal(before, tr.flat_p) and torch.equal(tb, tr.flat_t)
+
+
+def test_bf16_step_tracks_fp32():
+    """bf16 storage mode stays close to the fp32 parity mode over a few steps (loss components)."""
+    torch.manual_seed(0)
+    outs = {}
+    for dt in (torch.float32, torch.bfloat16):
+        cfg = TrainConfig(model="vnet", labeled_bs=1, batch_size=2, dtype=dt, seed=7)
+        tr = DyconTrainer(cfg, DEV)
+        gen = torch.Generator(device=DEV).manual_seed(5)
+        rows = []
+        for i in range(3):
+            vol = torch.randn(2, 1, 32, 32, 32, device=DEV, generator=gen)
+            lab = (torch.rand(2, 32, 32, 32, device=DEV, generator=gen) > 0.7).long()
+            noise = torch.clamp(torch.randn(2, 1, 32, 32, 32, device=DEV, generator=gen) * 0.1, -0.2, 0.2)
+            o = tr.step(vol, lab, noise=noise, s_drop=DropoutSpec("off"), t_drop=DropoutSpec("off"))
+            rows.append([float(o[k]) for k in ("loss", "ce", "dice", "cons", "fecl", "uncl")])
+        outs[dt] = np.array(rows)
+    np.testing.assert_allclose(outs[torch.bfloat16], outs[torch.float32], rtol=5e-2, atol=5e-3)
+
+
+def test_philox_step_runs_and_is_reproducible():
+    res = []
+    for _ in range(2):
+        cfg = TrainConfig(model="vnet", labeled_bs=1, batch_size=2, dtype=torch.bfloat16, seed=3)
+        tr = DyconTrainer(cfg, DEV)
+        gen = torch.Generator(device=DEV).manual_seed(1)
+        vol = torch.randn(2, 1, 32, 32, 32, device=DEV, generator=gen)
+        lab = (torch.rand(2, 32, 32, 32, device=DEV, generator=gen) > 0.7).long()
+        o = tr.step(vol, lab)
+        o = tr.step(vol, lab)
+        res.append((float(o["loss"]), tr.flat_p.clone()))
+    assert np.isfinite(res[0][0])
+    assert res[0][0] == pytest.approx(res[1][0], rel=1e-5)
