@@ -93,9 +93,15 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
+    def note(msg):
+        if rank == 0:
+            print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+    note("warm-up")
     for _ in range(args.warmup):
         tr.step(vol, lab)
     barrier()
+    note("timed region")
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = tr.step(vol, lab)
@@ -107,6 +113,7 @@ def main():
         dt = float(t)
     ms_per_step = dt / args.steps * 1e3
     value = args.batch * world * args.steps / dt
+    note(f"{ms_per_step:.2f} ms/step, {value:.2f} volumes/s")
 
     # ---- per-kernel roofline (HIP events on the launch stream, a few extra un-timed steps)
     roofline = None
@@ -135,7 +142,9 @@ def main():
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        note("cpu baseline (oracle on host cores)")
         cpu = cpu_baseline(args.model, patch, 1337)
+        note("done")
 
     if rank == 0:
         line = {"metric": "train volumes/sec (96^3 patch)", "value": value, "unit": "volumes/s", "n_gpus": world, "steps": args.steps,

@@ -27,7 +27,7 @@ SIGNATURES = {
     "dycon_conv_gemm": (I, [P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, P]),
     "dycon_conv_direct": (I, [P, I, P, P, P, I, I, I, I, I, I, I, I, I, P]),
     "dycon_conv_wgrad_workspace": (Z, [I, I, I, I, I, I, I]),
-    "dycon_conv_wgrad": (I, [P, I, P, I, P, I, I, I, I, I, I, I, L, L, L, P, Z, P]),
+    "dycon_conv_wgrad": (I, [P, I, P, I, P, P, I, I, I, I, I, I, I, L, L, L, P, Z, P]),
     "dycon_colsum_workspace": (Z, [L, I]),
     "dycon_colsum": (I, [P, I, P, L, I, P, Z, P]),
     "dycon_norm_workspace": (Z, [I, L, I]),

@@ -294,6 +294,141 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const TX* __restrict__ 
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// k=3 weight gradient on the bf16 matrix cores.
+//
+//   dW[t][ci][co] = sum_voxels X[voxel + off(t)][ci] * G[voxel][co]        (K = voxels)
+//
+// Both MFMA operands need the voxel index contiguous per lane, the opposite of the NDHWC memory order, so
+// tiles are staged through LDS in their natural [voxel][channel] order (16-byte global loads) and read
+// back TRANSPOSED by ds_read_b64_tr_b16: each 16-lane group fetches 4 voxels x 16 channels and every
+// lane receives its channel's 4 voxels.  One workgroup = one 16-channel ci tile x up to 64 co, walking
+// 4x4x8-voxel tiles (halo 6x6x10); the four waves split the 27 taps, so each wave keeps 7 x NT
+// accumulator tiles in registers across ALL its voxel tiles and nothing is reduced across waves.
+// The bias gradient (column sums of G) rides along in wave 0 of the ci-tile-0 workgroups.
+// ------------------------------------------------------------------------------------------------
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
+
+constexpr int WG_TZ = 4, WG_TY = 4, WG_TX = 8;                       // voxel tile
+constexpr int WG_HZ = WG_TZ + 2, WG_HY = WG_TY + 2, WG_HX = WG_TX + 2;   // halo tile
+constexpr int WG_NV = WG_TZ * WG_TY * WG_TX;                          // 128 voxels = 4 MFMA k-steps
+constexpr int WG_NH = WG_HZ * WG_HY * WG_HX;                          // 360 halo voxels
+
+__device__ __forceinline__ bf16x8 tr_frag(const unsigned short* lds_lo, const unsigned short* lds_hi) {
+    const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)lds_lo);
+    const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)lds_hi);
+    const s16x8 t = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    return __builtin_bit_cast(bf16x8, t);
+}
+
+template <int NT>
+__global__ __launch_bounds__(256, 2) void wgrad_k3_bf16_kernel(const bf16* __restrict__ X, const bf16* __restrict__ GY,
+                                                            float* __restrict__ part, float* __restrict__ bias_part, int B, int D,
+                                                            int H, int W, int Cin, int Cout, int nCoBlk, int nTiles, int tilesZ,
+                                                            int tilesY, int tilesX) {
+    constexpr int CB = 16 * NT;
+    __shared__ __attribute__((aligned(16))) unsigned short Xh[WG_NH * 16];
+    __shared__ __attribute__((aligned(16))) unsigned short Gt[WG_NV * CB];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int kg = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
+    const int ci0 = (blockIdx.x / nCoBlk) * 16;
+    const int co0 = (blockIdx.x % nCoBlk) * CB;
+    const int ntaps = wave < 3 ? 7 : 6;                 // taps wave, wave+4, ...
+    f32x4 acc[7][NT];
+#pragma unroll
+    for (int a = 0; a < 7; ++a)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[a][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float bsum[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) bsum[j] = 0.f;
+    const bool do_bias = bias_part != nullptr && ci0 == 0 && wave == 0;
+
+    for (int tile = blockIdx.y; tile < nTiles; tile += gridDim.y) {
+        int r = tile;
+        const int tx = r % tilesX; r /= tilesX;
+        const int ty = r % tilesY; r /= tilesY;
+        const int tz = r % tilesZ;
+        const int b = r / tilesZ;
+        const int z0 = tz * WG_TZ, y0 = ty * WG_TY, x0 = tx * WG_TX;
+        __syncthreads();   // previous tile fully consumed
+        // ---- stage X halo: 360 voxels x 32 B (two 16-B pieces each)
+        for (int e = threadIdx.x; e < WG_NH * 2; e += 256) {
+            const int hv = e >> 1, half = e & 1;
+            const int hx = hv % WG_HX, hy = (hv / WG_HX) % WG_HY, hz = hv / (WG_HX * WG_HY);
+            const int z = z0 + hz - 1, y = y0 + hy - 1, x = x0 + hx - 1;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if ((unsigned)z < (unsigned)D && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W)
+                v = *reinterpret_cast<const uint4*>(X + ((((long long)b * D + z) * H + y) * W + x) * Cin + ci0 + 8 * half);
+            *reinterpret_cast<uint4*>(Xh + hv * 16 + 8 * half) = v;
+        }
+        // ---- stage G tile: 128 voxels x CB channels
+        for (int e = threadIdx.x; e < WG_NV * (CB / 8); e += 256) {
+            const int v8 = e % (CB / 8), vv = e / (CB / 8);
+            const int vx = vv % WG_TX, vy = (vv / WG_TX) % WG_TY, vz = vv / (WG_TX * WG_TY);
+            const int z = z0 + vz, y = y0 + vy, x = x0 + vx;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (z < D && y < H && x < W && co0 + 8 * v8 < Cout)
+                v = *reinterpret_cast<const uint4*>(GY + ((((long long)b * D + z) * H + y) * W + x) * Cout + co0 + 8 * v8);
+            *reinterpret_cast<uint4*>(Gt + vv * CB + 8 * v8) = v;
+        }
+        __syncthreads();
+        // ---- 4 k-steps of 32 voxels: lane group kg owns x-row (z, y) = ((4s+kg)>>2, (4s+kg)&3), voxels x = 0..7
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int row = 4 * s + kg, z = row >> 2, y = row & 3;
+            bf16x8 bfr[NT];
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const unsigned short* g0 = Gt + (row * 8 + q) * CB + 16 * j + 4 * p;
+                bfr[j] = tr_frag(g0, g0 + 4 * CB);
+                if (do_bias) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) bsum[j] += (float)bfr[j][e];
+                }
+            }
+#pragma unroll
+            for (int a = 0; a < 7; ++a) {
+                if (a < ntaps) {
+                    const int t = wave + 4 * a;
+                    const int dz = t / 9, dy = (t / 3) % 3, dx = t % 3;
+                    const unsigned short* a0 = Xh + (((z + dz) * WG_HY + (y + dy)) * WG_HX + q + dx) * 16 + 4 * p;
+                    const bf16x8 afr = tr_frag(a0, a0 + 4 * 16);
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) acc[a][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr, bfr[j], acc[a][j], 0, 0, 0);
+                }
+            }
+        }
+    }
+    // ---- partial[split][t][ci][co]; D tile: row (ci) = 4*kg + reg, col (co) = lane & 15
+    const int col = lane & 15;
+    float* dst = part + (long long)blockIdx.y * 27 * Cin * Cout;
+#pragma unroll
+    for (int a = 0; a < 7; ++a) {
+        if (a >= ntaps) continue;
+        const int t = wave + 4 * a;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int co = co0 + 16 * j + col;
+            if (co >= Cout) continue;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) dst[((long long)t * Cin + ci0 + 4 * kg + i) * Cout + co] = acc[a][j][i];
+        }
+    }
+    if (do_bias) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            float v = bsum[j];
+            v += __shfl_xor(v, 16, 64);
+            v += __shfl_xor(v, 32, 64);
+            const int co = co0 + 16 * j + col;
+            if (kg == 0 && co < Cout) bias_part[(long long)blockIdx.y * Cout + co] = v;
+        }
+    }
+}
+
 // skinny weight gradient: thread j owns output element (t, ci, co); the block walks a voxel slice
 template <typename TX, typename TG, int MODE>
 __global__ __launch_bounds__(256) void conv_wgrad_direct_kernel(const TX* __restrict__ X, const TG* __restrict__ GY,
@@ -308,30 +443,46 @@ __global__ __launch_bounds__(256) void conv_wgrad_direct_kernel(const TX* __rest
     const long long m_end = min(M, m_beg + rows_per_split);
     if (j >= L) return;
     const int co = j % Cout, ci = (j / Cout) % Cin, t = j / (Cout * Cin);
-    float acc = 0.f;
-    long long q = m_beg;
-    int xo = (int)(q % Wo); q /= Wo;
-    int yo = (int)(q % Ho); q /= Ho;
-    int zo = (int)(q % Do);
-    int bo = (int)(q / Do);
-    for (long long m = m_beg; m < m_end; ++m) {
-        int zi, yi, xi;
-        if (src_voxel<MODE>(t, zo, yo, xo, Di, Hi, Wi, zi, yi, xi))
-            acc += ldf(X + ((((long long)bo * Di + zi) * Hi + yi) * Wi + xi) * Cin + ci) * ldf(GY + m * Cout + co);
-        if (++xo == Wo) { xo = 0; if (++yo == Ho) { yo = 0; if (++zo == Do) { zo = 0; ++bo; } } }
+    // four interleaved voxel streams: four independent load->fma chains in flight per thread
+    float acc4[4] = {0.f, 0.f, 0.f, 0.f};
+    for (long long m0 = m_beg; m0 < m_end; m0 += 4) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const long long m = m0 + u;
+            if (m >= m_end) continue;
+            long long q = m;
+            const int xo = (int)(q % Wo); q /= Wo;
+            const int yo = (int)(q % Ho); q /= Ho;
+            const int zo = (int)(q % Do);
+            const int bo = (int)(q / Do);
+            int zi, yi, xi;
+            if (src_voxel<MODE>(t, zo, yo, xo, Di, Hi, Wi, zi, yi, xi))
+                acc4[u] += ldf(X + ((((long long)bo * Di + zi) * Hi + yi) * Wi + xi) * Cin + ci) * ldf(GY + m * Cout + co);
+        }
     }
+    const float acc = (acc4[0] + acc4[1]) + (acc4[2] + acc4[3]);
     part[(long long)blockIdx.x * L + j] = acc;
 }
 
 // out[map(i)] = sum_p part[p*L + i], i = (t*Cin + ci)*Cout + co, map = t*s_t + ci*s_c + co*s_n
-__global__ void reduce_partials_kernel(const float* __restrict__ part, int P, int L, float* __restrict__ out, int Cin,
-                                       int Cout, long long s_t, long long s_c, long long s_n) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= L) return;
+// 256 threads = 32 outputs x 8 partial lanes (ordered, deterministic): short dependent chains even for P = 256
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ part, int P, int L, float* __restrict__ out,
+                                                              int Cin, int Cout, long long s_t, long long s_c, long long s_n) {
+    __shared__ float sm[8][33];
+    const int o = threadIdx.x & 31, pl = threadIdx.x >> 5;
+    const int i = blockIdx.x * 32 + o;
     float s = 0.f;
-    for (int p = 0; p < P; ++p) s += part[(long long)p * L + i];
-    const int co = i % Cout, ci = (i / Cout) % Cin, t = i / (Cout * Cin);
-    out[t * s_t + ci * s_c + co * s_n] = s;
+    if (i < L)
+        for (int p = pl; p < P; p += 8) s += part[(long long)p * L + i];
+    sm[pl][o] = s;
+    __syncthreads();
+    if (pl == 0 && i < L) {
+        float tot = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) tot += sm[k][o];
+        const int co = i % Cout, ci = (i / Cout) % Cin, t = i / (Cout * Cin);
+        out[t * s_t + ci * s_c + co * s_n] = tot;
+    }
 }
 
 // column sums of an (rows, C) matrix, stage 1: partial[blk][c]
@@ -489,16 +640,50 @@ static WgradPlan wgrad_plan(int mode, int B, int Di, int Hi, int Wi, int Cin, in
         p.splits = (int)((M + rps - 1) / rps);
         p.rows_per_split = rps;
     } else {
-        long long rps = 4096;
+        long long rps = 1024;
         p.splits = (int)((M + rps - 1) / rps);
         p.rows_per_split = rps;
     }
     return p;
 }
 
+extern "C" size_t dycon_colsum_workspace(long long rows, int C);
+extern "C" int dycon_colsum(const void* x, int dtype, float* out, long long rows, int C, float* workspace, size_t ws_bytes,
+                            dycon_stream_t stream);
+
+// k=3 bf16 plan: tiles and voxel-tile splits (partials capped at ~24 MB)
+struct WgradK3Plan { int tilesZ, tilesY, tilesX, nTiles, gx, nCoBlk, NT, splits; };
+static WgradK3Plan wgrad_k3_plan(int B, int D, int H, int W, int Cin, int Cout) {
+    WgradK3Plan p;
+    p.tilesZ = cdiv(D, WG_TZ); p.tilesY = cdiv(H, WG_TY); p.tilesX = cdiv(W, WG_TX);
+    p.nTiles = B * p.tilesZ * p.tilesY * p.tilesX;
+    p.NT = Cout >= 64 ? 4 : Cout / 16;
+    p.nCoBlk = cdiv(Cout, 16 * p.NT);
+    p.gx = (Cin / 16) * p.nCoBlk;
+    const long long L = 27LL * Cin * Cout;
+    long long s = 2048 / p.gx;
+    const long long cap = (24LL << 20) / (4 * L);
+    if (s > cap) s = cap;
+    if (s > p.nTiles) s = p.nTiles;
+    if (s < 1) s = 1;
+    p.splits = (int)s;
+    return p;
+}
+static bool wgrad_k3_ok(int mode, int Cin, int Cout) {
+    return mode == DYCON_CONV_K3 && Cin % 16 == 0 && Cout % 16 == 0 && (Cout == 16 || Cout == 32 || Cout % 64 == 0);
+}
+
 extern "C" size_t dycon_conv_wgrad_workspace(int mode, int B, int Di, int Hi, int Wi, int Cin, int Cout) {
     const WgradPlan p = wgrad_plan(mode, B, Di, Hi, Wi, Cin, Cout);
-    return (size_t)p.splits * p.L * sizeof(float);
+    size_t need = (size_t)p.splits * p.L * sizeof(float);
+    if (wgrad_k3_ok(mode, Cin, Cout)) {
+        const WgradK3Plan k = wgrad_k3_plan(B, Di, Hi, Wi, Cin, Cout);
+        const size_t n2 = ((size_t)k.splits * p.L + (size_t)k.splits * Cout) * sizeof(float);
+        if (n2 > need) need = n2;
+    }
+    int Do, Ho, Wo;
+    row_grid(mode, Di, Hi, Wi, Do, Ho, Wo);
+    return need + dycon_colsum_workspace((long long)B * Do * Ho * Wo, Cout) + 64;   // room for the un-fused bias gradient
 }
 
 template <typename TX, typename TG>
@@ -527,23 +712,48 @@ static void launch_wgrad(const void* x, const void* gy, float* part, int mode, c
     }
 }
 
-extern "C" int dycon_conv_wgrad(const void* x, int x_dtype, const void* gy, int g_dtype, float* dw, int mode, int B, int Di,
-                                int Hi, int Wi, int Cin, int Cout, long long s_t, long long s_c, long long s_n,
+extern "C" int dycon_conv_wgrad(const void* x, int x_dtype, const void* gy, int g_dtype, float* dw, float* dbias, int mode, int B,
+                                int Di, int Hi, int Wi, int Cin, int Cout, long long s_t, long long s_c, long long s_n,
                                 float* workspace, size_t ws_bytes, dycon_stream_t stream) {
     DYCON_REQUIRE(x && gy && dw && workspace, "conv_wgrad: null pointer");
     DYCON_REQUIRE(B > 0 && Di > 0 && Hi > 0 && Wi > 0 && Cin > 0 && Cout > 0, "conv_wgrad: bad shape");
     DYCON_REQUIRE(mode >= 0 && mode <= 2, "conv_wgrad: bad mode %d", mode);
+    DYCON_REQUIRE(ws_bytes >= dycon_conv_wgrad_workspace(mode, B, Di, Hi, Wi, Cin, Cout), "conv_wgrad: workspace too small");
     const WgradPlan p = wgrad_plan(mode, B, Di, Hi, Wi, Cin, Cout);
-    DYCON_REQUIRE(ws_bytes >= (size_t)p.splits * p.L * sizeof(float), "conv_wgrad: workspace too small (%zu < %zu)", ws_bytes,
-                  (size_t)p.splits * p.L * sizeof(float));
+    if (x_dtype == DYCON_BF16 && g_dtype == DYCON_BF16 && wgrad_k3_ok(mode, Cin, Cout)) {
+        const WgradK3Plan k = wgrad_k3_plan(B, Di, Hi, Wi, Cin, Cout);
+        float* bpart = dbias ? workspace + (size_t)k.splits * p.L : nullptr;
+        dim3 grid(k.gx, k.splits);
+#define DYCON_WK3(NTV) \
+    wgrad_k3_bf16_kernel<NTV><<<grid, 256, 0, stream>>>((const bf16*)x, (const bf16*)gy, workspace, bpart, B, Di, Hi, Wi, Cin, Cout, k.nCoBlk, k.nTiles, k.tilesZ, k.tilesY, k.tilesX)
+        if (k.NT == 1) DYCON_WK3(1);
+        else if (k.NT == 2) DYCON_WK3(2);
+        else DYCON_WK3(4);
+#undef DYCON_WK3
+        DYCON_LAUNCH_CHECK();
+        reduce_partials_kernel<<<cdiv(p.L, 32), 256, 0, stream>>>(workspace, k.splits, p.L, dw, Cin, Cout, s_t, s_c, s_n);
+        DYCON_LAUNCH_CHECK();
+        if (dbias) {
+            reduce_partials_kernel<<<cdiv(Cout, 32), 256, 0, stream>>>(bpart, k.splits, Cout, dbias, 1, Cout, 0, 0, 1);
+            DYCON_LAUNCH_CHECK();
+        }
+        return DYCON_OK;
+    }
     if (x_dtype == DYCON_F32 && g_dtype == DYCON_F32) launch_wgrad<float, float>(x, gy, workspace, mode, p, B, Di, Hi, Wi, Cin, Cout, stream);
     else if (x_dtype == DYCON_BF16 && g_dtype == DYCON_BF16) launch_wgrad<bf16, bf16>(x, gy, workspace, mode, p, B, Di, Hi, Wi, Cin, Cout, stream);
     else if (x_dtype == DYCON_BF16 && g_dtype == DYCON_F32) launch_wgrad<bf16, float>(x, gy, workspace, mode, p, B, Di, Hi, Wi, Cin, Cout, stream);
     else if (x_dtype == DYCON_F32 && g_dtype == DYCON_BF16) launch_wgrad<float, bf16>(x, gy, workspace, mode, p, B, Di, Hi, Wi, Cin, Cout, stream);
     else { dycon_set_error("conv_wgrad: bad dtypes"); return DYCON_ERR_INVALID; }
     DYCON_LAUNCH_CHECK();
-    reduce_partials_kernel<<<cdiv(p.L, 256), 256, 0, stream>>>(workspace, p.splits, p.L, dw, Cin, Cout, s_t, s_c, s_n);
+    reduce_partials_kernel<<<cdiv(p.L, 32), 256, 0, stream>>>(workspace, p.splits, p.L, dw, Cin, Cout, s_t, s_c, s_n);
     DYCON_LAUNCH_CHECK();
+    if (dbias) {   // un-fused bias gradient: column sums of gy, partials behind the weight partials
+        int Do, Ho, Wo;
+        row_grid(mode, Di, Hi, Wi, Do, Ho, Wo);
+        const long long rows = (long long)B * Do * Ho * Wo;
+        float* cws = workspace + (size_t)p.splits * p.L;
+        return dycon_colsum(gy, g_dtype, dbias, rows, Cout, cws, dycon_colsum_workspace(rows, Cout), stream);
+    }
     return DYCON_OK;
 }
 
@@ -569,7 +779,7 @@ extern "C" int dycon_colsum(const void* x, int dtype, float* out, long long rows
     DYCON_REQUIRE(ws_bytes >= (size_t)blocks * C * sizeof(float), "colsum: workspace too small");
     DYCON_DISPATCH(dtype, { colsum_kernel<T><<<blocks, 256, 0, stream>>>((const T*)x, workspace, rows, C, rpb); });
     DYCON_LAUNCH_CHECK();
-    reduce_partials_kernel<<<cdiv(C, 256), 256, 0, stream>>>(workspace, blocks, C, out, 1, C, 0, 0, 1);
+    reduce_partials_kernel<<<cdiv(C, 32), 256, 0, stream>>>(workspace, blocks, C, out, 1, C, 0, 0, 1);
     DYCON_LAUNCH_CHECK();
     return DYCON_OK;
 }

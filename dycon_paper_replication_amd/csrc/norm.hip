@@ -95,20 +95,23 @@ __global__ __launch_bounds__(256) void norm_partial_kernel(const T* __restrict__
     }
 }
 
-// ---- stage 2 (forward): mean / rstd per (n, g) (+ BatchNorm running statistics)
-__global__ void norm_finalize_stats_kernel(const float* __restrict__ part, int Nb, int chunks, int C, int G, long long V,
-                                           float eps, float* __restrict__ stats, float* running_mean, float* running_var,
-                                           float momentum) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= Nb * G) return;
+// ---- stage 2 (forward): mean / rstd per (n, g) (+ BatchNorm running statistics).  One wave per (n, g).
+__global__ __launch_bounds__(64) void norm_finalize_stats_kernel(const float* __restrict__ part, int Nb, int chunks, int C, int G,
+                                                                 long long V, float eps, float* __restrict__ stats,
+                                                                 float* running_mean, float* running_var, float momentum) {
+    const int i = blockIdx.x, lane = threadIdx.x;
     const int n = i / G, g = i % G, cpg = C / G;
     double s0 = 0.0, s1 = 0.0;
-    for (int ch = 0; ch < chunks; ++ch)
-        for (int c = g * cpg; c < (g + 1) * cpg; ++c) {
-            const float* p = part + ((((long long)n * chunks + ch) * C) + c) * 2;
-            s0 += p[0];
-            s1 += p[1];
-        }
+    const int items = chunks * cpg;
+    for (int e = lane; e < items; e += 64) {
+        const int ch = e / cpg, c = g * cpg + e % cpg;
+        const float* p = part + ((((long long)n * chunks + ch) * C) + c) * 2;
+        s0 += p[0];
+        s1 += p[1];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { s0 += __shfl_xor(s0, o, 64); s1 += __shfl_xor(s1, o, 64); }
+    if (lane != 0) return;
     const double cnt = (double)V * cpg;
     const double mean = s0 / cnt;
     double var = s1 / cnt - mean * mean;
@@ -122,39 +125,36 @@ __global__ void norm_finalize_stats_kernel(const float* __restrict__ part, int N
     }
 }
 
-// ---- stage 2 (backward): per-(n,g) {A, B} and per-channel dgamma/dbeta
-__global__ void norm_finalize_bwd_kernel(const float* __restrict__ part, int Nb, int chunks, int C, int G,
-                                         const float* __restrict__ gamma, float* __restrict__ ab, float* dgamma,
-                                         float* dbeta) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    const int cpg = C / G;
-    if (i < Nb * G) {
-        const int n = i / G, g = i % G;
-        double A = 0.0, Bq = 0.0;
-        for (int c = g * cpg; c < (g + 1) * cpg; ++c) {
-            double s0 = 0.0, s1 = 0.0;
-            for (int ch = 0; ch < chunks; ++ch) {
-                const float* p = part + ((((long long)n * chunks + ch) * C) + c) * 2;
-                s0 += p[0];
-                s1 += p[1];
-            }
+// ---- stage 2 (backward): blocks [0, Nb*G): per-(n,g) {A, B}; blocks [Nb*G, Nb*G + C): per-channel dgamma/dbeta
+__global__ __launch_bounds__(64) void norm_finalize_bwd_kernel(const float* __restrict__ part, int Nb, int chunks, int C, int G,
+                                                               const float* __restrict__ gamma, float* __restrict__ ab,
+                                                               float* dgamma, float* dbeta) {
+    const int lane = threadIdx.x, cpg = C / G;
+    double s0 = 0.0, s1 = 0.0;
+    if ((int)blockIdx.x < Nb * G) {
+        const int i = blockIdx.x, n = i / G, g = i % G;
+        const int items = chunks * cpg;
+        for (int e = lane; e < items; e += 64) {
+            const int ch = e / cpg, c = g * cpg + e % cpg;
+            const float* p = part + ((((long long)n * chunks + ch) * C) + c) * 2;
             const double gm = gamma ? (double)gamma[c] : 1.0;
-            A += gm * s0;
-            Bq += gm * s1;
+            s0 += gm * p[0];
+            s1 += gm * p[1];
         }
-        ab[(long long)i * 2] = (float)A;
-        ab[(long long)i * 2 + 1] = (float)Bq;
-    }
-    if (i < C && (dgamma || dbeta)) {
-        double s0 = 0.0, s1 = 0.0;
-        for (int n = 0; n < Nb; ++n)
-            for (int ch = 0; ch < chunks; ++ch) {
-                const float* p = part + ((((long long)n * chunks + ch) * C) + i) * 2;
-                s0 += p[0];
-                s1 += p[1];
-            }
-        if (dbeta) dbeta[i] = (float)s0;
-        if (dgamma) dgamma[i] = (float)s1;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { s0 += __shfl_xor(s0, o, 64); s1 += __shfl_xor(s1, o, 64); }
+        if (lane == 0) { ab[(long long)i * 2] = (float)s0; ab[(long long)i * 2 + 1] = (float)s1; }
+    } else {
+        const int c = blockIdx.x - Nb * G;
+        const int items = Nb * chunks;
+        for (int e = lane; e < items; e += 64) {
+            const float* p = part + ((long long)e * C + c) * 2;   // (n, chunk) pairs are contiguous blocks of C
+            s0 += p[0];
+            s1 += p[1];
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { s0 += __shfl_xor(s0, o, 64); s1 += __shfl_xor(s1, o, 64); }
+        if (lane == 0) { if (dbeta) dbeta[c] = (float)s0; if (dgamma) dgamma[c] = (float)s1; }
     }
 }
 
@@ -185,7 +185,7 @@ __global__ __launch_bounds__(256) void norm_apply_kernel(const T* __restrict__ X
 #pragma unroll
         for (int k = 0; k < VN; ++k) {
             float v = x.get(k) * ss[c0 + k] + ss[C + c0 + k];
-            if (relu) v = fmaxf(v, 0.f);
+            if (relu) v = v < 0.f ? 0.f : v;   // NaN-propagating, like torch.relu (fmaxf would swallow a NaN)
             if (skip) v += s.get(k);
             y.set(k, v);
         }
@@ -266,8 +266,7 @@ extern "C" int dycon_norm_stats(const void* x, int dtype, int Nb, long long V, i
                                                             nullptr, nullptr, 0, 0);
     });
     DYCON_LAUNCH_CHECK();
-    norm_finalize_stats_kernel<<<cdiv((long long)Nb * G, 128), 128, 0, stream>>>(workspace, Nb, p.chunks, C, G, V, eps, stats,
-                                                                                 running_mean, running_var, momentum);
+    norm_finalize_stats_kernel<<<Nb * G, 64, 0, stream>>>(workspace, Nb, p.chunks, C, G, V, eps, stats, running_mean, running_var, momentum);
     DYCON_LAUNCH_CHECK();
     return DYCON_OK;
 }
@@ -306,8 +305,8 @@ extern "C" int dycon_norm_bwd(const void* src, int from_y, const void* gy, void*
                                                             stats, gamma, beta, relu, from_y);
     });
     DYCON_LAUNCH_CHECK();
-    const int nfin = (Nb * G > C ? Nb * G : C);
-    norm_finalize_bwd_kernel<<<cdiv(nfin, 128), 128, 0, stream>>>(workspace, Nb, p.chunks, C, G, gamma, ab, dgamma, dbeta);
+    const int nfin = Nb * G + ((dgamma || dbeta) ? C : 0);
+    norm_finalize_bwd_kernel<<<nfin, 64, 0, stream>>>(workspace, Nb, p.chunks, C, G, gamma, ab, dgamma, dbeta);
     DYCON_LAUNCH_CHECK();
     DYCON_DISPATCH(dtype, {
         dim3 grid2(apply_grid(V, C, Vec16<T>::N), Nb);

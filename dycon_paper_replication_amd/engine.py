@@ -193,11 +193,11 @@ class Engine:
             def bwd():
                 gy = self._take(y)
                 gw, gb = self.g[name + ".weight"], self.g[name + ".bias"]
-                ops.colsum(gy, gb)
-                if kind == "deconv":   # dW[ci][co][t] = sum_m x[m,ci] * gy[2m+t,co]
+                if kind == "deconv":   # dW[ci][co][t] = sum_m x[m,ci] * gy[2m+t,co]   (roles of x and gy swapped)
+                    ops.colsum(gy, gb)
                     ops.conv_wgrad(gy, x, gw, CONV_K2S2, 1, 8, Cout * 8)
-                else:
-                    ops.conv_wgrad(x, gy, gw, mode, 1 if T > 1 else 0, T, Cin * T)
+                else:                  # bias gradient = column sums of gy, fused into the wgrad pass
+                    ops.conv_wgrad(x, gy, gw, mode, 1 if T > 1 else 0, T, Cin * T, dbias=gb)
                 if not need_gx:
                     return
                 cur = self.G.get(id(x))

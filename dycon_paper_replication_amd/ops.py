@@ -133,8 +133,9 @@ def conv_direct(x, w_tcn, bias, mode, N, out_dtype, out=None, accumulate=False):
     return out
 
 
-def conv_wgrad(x, gy, dw, mode, s_t, s_c, s_n):
-    """dw[t*s_t + c*s_c + n*s_n] = sum_rows x[src(row,t), c] * gy[row, n]; dw is an fp32 tensor (any shape)."""
+def conv_wgrad(x, gy, dw, mode, s_t, s_c, s_n, dbias=None):
+    """dw[t*s_t + c*s_c + n*s_n] = sum_rows x[src(row,t), c] * gy[row, n]; dw is an fp32 tensor (any shape).
+    dbias (optional, fp32 (Cout,)): column sums of gy, fused into the same pass where the kernel allows."""
     B, D, H, W, Cin = x.shape
     Cout = gy.shape[-1]
     nbytes = query("dycon_conv_wgrad_workspace", mode, B, D, H, W, Cin, Cout)
@@ -142,7 +143,7 @@ def conv_wgrad(x, gy, dw, mode, s_t, s_c, s_n):
     taps = {CONV_K3: 27, CONV_K2S2: 8, CONV_1X1: 1}[mode]
     with _Region("conv_wgrad", x.numel() * _es(x) + gy.numel() * _es(gy) + taps * Cin * Cout * 4,
                  2 * (gy.numel() // Cout) * taps * Cin * Cout):
-        call("dycon_conv_wgrad", _p(x), dt(x), _p(gy), dt(gy), _p(dw), mode, B, D, H, W, Cin, Cout, s_t, s_c, s_n,
+        call("dycon_conv_wgrad", _p(x), dt(x), _p(gy), dt(gy), _p(dw), _p(dbias), mode, B, D, H, W, Cin, Cout, s_t, s_c, s_n,
              _p(ws), ws.numel() * 4, _s())
     return dw
 

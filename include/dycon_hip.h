@@ -74,12 +74,15 @@ int dycon_conv_direct(const void* x, int x_dtype, const float* w_tcn, const floa
                       int N, dycon_stream_t stream);
 
 /* weight gradient: dw[t*s_t + c*s_c + n*s_n] = sum_rows x[src(row,t), c] * gy[row, n]
- * (x on the input grid with Cin channels, gy on the output-row grid with Cout channels).
- * Two-stage, deterministic: per-split partials in `workspace`, then an ordered reduce. */
+ * (x on the input grid with Cin channels, gy on the output-row grid with Cout channels), and,
+ * when dbias != NULL, the bias gradient dbias[n] = sum_rows gy[row, n] (fused into the same
+ * pass over gy on the bf16 k=3 path).  Two-stage, deterministic: per-split partials in
+ * `workspace`, then an ordered reduce. */
 size_t dycon_conv_wgrad_workspace(int mode, int B, int Di, int Hi, int Wi, int Cin, int Cout);
-int dycon_conv_wgrad(const void* x, int x_dtype, const void* gy, int g_dtype, float* dw, int mode,
-                     int B, int Di, int Hi, int Wi, int Cin, int Cout, long long s_t, long long s_c,
-                     long long s_n, float* workspace, size_t ws_bytes, dycon_stream_t stream);
+int dycon_conv_wgrad(const void* x, int x_dtype, const void* gy, int g_dtype, float* dw, float* dbias,
+                     int mode, int B, int Di, int Hi, int Wi, int Cin, int Cout, long long s_t,
+                     long long s_c, long long s_n, float* workspace, size_t ws_bytes,
+                     dycon_stream_t stream);
 
 /* out[c] = sum_rows x[row, c]   (bias gradients; also per-channel sums) */
 size_t dycon_colsum_workspace(long long rows, int C);

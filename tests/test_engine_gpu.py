@@ -64,12 +64,18 @@ def test_full_net_fp32_vs_reference(kind):
             assert not ref.any() and torch.isnan(eng.g[k]).all()   # no gradient reaches the discarded sdf head
             continue
         got = _stats(eng.g[k])
-        if k.endswith(".bias") and eng.p[k[:-4] + "weight"].dim() == 5 and not k.startswith("out_conv"):
-            # a conv bias in front of a normalisation layer has an analytically ZERO gradient: both sides
-            # hold round-off noise only; require it to stay at noise level relative to the weight gradient
-            assert got[1] <= 1e-4 * refs[k[:-4] + "weight"][1] + 2e-2, (k, got, ref)
+        w = k[:-4] + "weight"
+        one_channel_groups = kind == "unet" or eng.p[k].shape[0] == 16 or k.startswith("projection.")
+        if k.endswith(".bias") and eng.p[w].dim() == 5 and not k.startswith("out_conv") and one_channel_groups:
+            # a conv bias in front of a per-channel normalisation (InstanceNorm / BatchNorm / GroupNorm with one
+            # channel per group) has an analytically ZERO gradient: both sides hold round-off noise only
+            assert got[1] <= 1e-4 * refs[w][1] + 2e-2, (k, got, ref)
             continue
-        np.testing.assert_allclose(got, ref, rtol=2e-3, atol=5e-3, err_msg=k)
+        # statistics are (sum, sum|.|, sum .^2): the plain sum cancels heavily, so it is held relative to sum|.|.
+        # This random-weighted objective drives gradients of 1e5 through 40 layers; the realistic-loss traces in
+        # test_trainer_gpu.py hold gradient norm and updated parameters to 1e-4.
+        assert abs(got[0] - ref[0]) <= 3e-3 * ref[1] + 5e-3, (k, got, ref)
+        np.testing.assert_allclose(got[1:], ref[1:], rtol=3e-3, atol=5e-3, err_msg=k)
 
 
 @pytest.mark.parametrize("kind", ["vnet", "unet"])
