@@ -24,7 +24,8 @@ SIGNATURES = {
     "dycon_bfrag_bytes": (Z, [I, I, I, I]),
     "dycon_pack_bfrag": (I, [P, P, I, I, I, I, I, L, L, L, L, I, P]),
     "dycon_pack_tcn": (I, [P, P, I, I, I, I, L, L, L, L, I, P]),
-    "dycon_conv_gemm": (I, [P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, P]),
+    "dycon_conv_gemm_workspace": (Z, [I, I, I, I, I, I, I, I, I]),
+    "dycon_conv_gemm": (I, [P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, P, Z, P]),
     "dycon_conv_direct": (I, [P, I, P, P, P, I, I, I, I, I, I, I, I, I, P]),
     "dycon_conv_wgrad_workspace": (Z, [I, I, I, I, I, I, I]),
     "dycon_conv_wgrad": (I, [P, I, P, I, P, P, I, I, I, I, I, I, I, L, L, L, P, Z, P]),

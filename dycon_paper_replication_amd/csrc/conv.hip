@@ -100,7 +100,8 @@ template <typename T, int MODE, bool SCATTER>
 __global__ __launch_bounds__(256) void conv_gemm_kernel(const T* __restrict__ X, const T* __restrict__ Wf,
                                                         const float* __restrict__ bias, T* __restrict__ Y, int B, int Di,
                                                         int Hi, int Wi, int Cin, int Do, int Ho, int Wo, int N, int Cout,
-                                                        int NT, int nKC, int accumulate) {
+                                                        int NT, int nKC, int accumulate, float* __restrict__ slab,
+                                                        int kc_per_split) {
     constexpr int G = Frag<T>::G, KC = Frag<T>::KC;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 15, kg = lane >> 4;
@@ -121,10 +122,13 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const T* __restrict__ X,
 #pragma unroll
     for (int j = 0; j < NTB; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    int c = G * kg, t = 0;  // this lane's (tap, channel) inside the flattened K = taps*Cin
-    while (c >= Cin) { c -= Cin; ++t; }
-    const T* wf = Wf + ((long long)nt0 * 64 + lane) * G;
-    for (int kc = 0; kc < nKC; ++kc) {
+    // split-K (small spatial levels): blockIdx.z owns k-chunks [kc0, kc1) and writes an fp32 partial slab
+    const int kc0 = slab ? blockIdx.z * kc_per_split : 0;
+    const int kc1 = slab ? min(nKC, kc0 + kc_per_split) : nKC;
+    const int kl = kc0 * KC + G * kg;          // this lane's position inside the flattened K = taps*Cin
+    int t = kl / Cin, c = kl - t * Cin;
+    const T* wf = Wf + (((long long)kc0 * NT + nt0) * 64 + lane) * G;
+    for (int kc = kc0; kc < kc1; ++kc) {
         Vec16<T> a;
         a.v = decltype(a.v){};
         if (mvalid && t < Tn) {
@@ -145,6 +149,20 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const T* __restrict__ X,
     }
 
     // epilogue: C/D layout of the 16x16 tile: column = lane&15, row = 4*(lane>>4) + i
+    if (slab) {
+        float* sl = slab + (long long)blockIdx.z * M * N;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const long long mo = (long long)blockIdx.x * 64 + wave * 16 + kg * 4 + i;
+            if (mo >= M) continue;
+#pragma unroll
+            for (int j = 0; j < NTB; ++j) {
+                const int n = (nt0 + j) * 16 + r;
+                if (nt0 + j < NT && n < N) sl[mo * N + n] = acc[j][i];
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const long long mo = (long long)blockIdx.x * 64 + wave * 16 + kg * 4 + i;
@@ -181,6 +199,18 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const T* __restrict__ X,
             if (accumulate) v += ldf(Y + off);
             stf(Y + off, v);
         }
+    }
+}
+
+// y[m, n] (+)= bias[n] + sum_z slab[z][m][n]   (ordered: deterministic)
+template <typename T>
+__global__ __launch_bounds__(256) void splitk_finish_kernel(const float* __restrict__ slab, int splits, long long MN, int N,
+                                                            const float* __restrict__ bias, T* __restrict__ Y, int accumulate) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < MN; i += (long long)gridDim.x * 256) {
+        float v = bias ? bias[i % N] : 0.f;
+        for (int z = 0; z < splits; ++z) v += slab[(long long)z * MN + i];
+        if (accumulate) v += ldf(Y + i);
+        stf(Y + i, v);
     }
 }
 
@@ -323,7 +353,7 @@ __device__ __forceinline__ bf16x8 tr_frag(const unsigned short* lds_lo, const un
     return __builtin_bit_cast(bf16x8, t);
 }
 
-template <int NT>
+template <int NT, bool CIN1>
 __global__ __launch_bounds__(256, 2) void wgrad_k3_bf16_kernel(const bf16* __restrict__ X, const bf16* __restrict__ GY,
                                                             float* __restrict__ part, float* __restrict__ bias_part, int B, int D,
                                                             int H, int W, int Cin, int Cout, int nCoBlk, int nTiles, int tilesZ,
@@ -354,7 +384,19 @@ __global__ __launch_bounds__(256, 2) void wgrad_k3_bf16_kernel(const bf16* __res
         const int b = r / tilesZ;
         const int z0 = tz * WG_TZ, y0 = ty * WG_TY, x0 = tx * WG_TX;
         __syncthreads();   // previous tile fully consumed
-        // ---- stage X halo: 360 voxels x 32 B (two 16-B pieces each)
+        // ---- stage X halo: 360 voxels x 32 B (two 16-B pieces each).  CIN1 (first layer, one input channel):
+        //      channel 0 carries x, channels 1..15 are zero, so the same MFMA body yields dW[:, 0, :]
+        if (CIN1) {
+            for (int hv = threadIdx.x; hv < WG_NH; hv += 256) {
+                const int hx = hv % WG_HX, hy = (hv / WG_HX) % WG_HY, hz = hv / (WG_HX * WG_HY);
+                const int z = z0 + hz - 1, y = y0 + hy - 1, x = x0 + hx - 1;
+                unsigned v0 = 0;
+                if ((unsigned)z < (unsigned)D && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W)
+                    v0 = reinterpret_cast<const unsigned short*>(X)[(((long long)b * D + z) * H + y) * W + x];
+                *reinterpret_cast<uint4*>(Xh + hv * 16) = make_uint4(v0, 0, 0, 0);
+                *reinterpret_cast<uint4*>(Xh + hv * 16 + 8) = make_uint4(0, 0, 0, 0);
+            }
+        } else
         for (int e = threadIdx.x; e < WG_NH * 2; e += 256) {
             const int hv = e >> 1, half = e & 1;
             const int hx = hv % WG_HX, hy = (hv / WG_HX) % WG_HY, hz = hv / (WG_HX * WG_HY);
@@ -414,7 +456,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_k3_bf16_kernel(const bf16* __res
             const int co = co0 + 16 * j + col;
             if (co >= Cout) continue;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) dst[((long long)t * Cin + ci0 + 4 * kg + i) * Cout + co] = acc[a][j][i];
+            for (int i = 0; i < 4; ++i)
+                if (ci0 + 4 * kg + i < Cin) dst[((long long)t * Cin + ci0 + 4 * kg + i) * Cout + co] = acc[a][j][i];
         }
     }
     if (do_bias) {
@@ -462,6 +505,97 @@ __global__ __launch_bounds__(256) void conv_wgrad_direct_kernel(const TX* __rest
     }
     const float acc = (acc4[0] + acc4[1]) + (acc4[2] + acc4[3]);
     part[(long long)blockIdx.x * L + j] = acc;
+}
+
+// 1x1 weight gradient for the 2-class heads (Cin = 16, Cout = 2): every thread keeps all CIN*COUT partial
+// products in registers over a strided voxel stream (one 32-B + one 8-B load per voxel), block-reduces them
+// through LDS and writes one partial row.  Pure HBM stream.
+template <typename TX, typename TG, int CIN, int COUT>
+__global__ __launch_bounds__(256) void wgrad_1x1_skinny_kernel(const TX* __restrict__ X, const TG* __restrict__ GY,
+                                                               float* __restrict__ part, long long M) {
+    __shared__ float red[4][CIN * COUT];
+    float acc[CIN * COUT];
+#pragma unroll
+    for (int k = 0; k < CIN * COUT; ++k) acc[k] = 0.f;
+    for (long long m = (long long)blockIdx.x * 256 + threadIdx.x; m < M; m += (long long)gridDim.x * 256) {
+        float xv[CIN], gv[COUT];
+        constexpr int VN = Vec16<TX>::N;
+#pragma unroll
+        for (int c0 = 0; c0 < CIN; c0 += VN) {
+            const Vec16<TX> v = ld16(X + m * CIN + c0);
+#pragma unroll
+            for (int k = 0; k < VN; ++k) xv[c0 + k] = v.get(k);
+        }
+#pragma unroll
+        for (int k = 0; k < COUT; ++k) gv[k] = ldf(GY + m * COUT + k);
+#pragma unroll
+        for (int c = 0; c < CIN; ++c)
+#pragma unroll
+            for (int k = 0; k < COUT; ++k) acc[c * COUT + k] += xv[c] * gv[k];
+    }
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < CIN * COUT; ++k) {
+        const float v = wave_sum(acc[k]);
+        if (lane == 0) red[wv][k] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < CIN * COUT)   // partial layout [t=0][ci][co]
+        part[(long long)blockIdx.x * CIN * COUT + threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+
+// y[m, 0..COUT) = bias + sum_c x[m, c] * W[c][.]   (Cin = 16 -> 2 logits: one 32-B load per voxel)
+template <typename TI, int CIN, int COUT>
+__global__ __launch_bounds__(256) void head_1x1_fwd_kernel(const TI* __restrict__ X, const float* __restrict__ W,
+                                                           const float* __restrict__ bias, float* __restrict__ Y, long long M) {
+    __shared__ float w[CIN * COUT + COUT];
+    if (threadIdx.x < CIN * COUT) w[threadIdx.x] = W[threadIdx.x];
+    if (threadIdx.x < COUT) w[CIN * COUT + threadIdx.x] = bias ? bias[threadIdx.x] : 0.f;
+    __syncthreads();
+    constexpr int VN = Vec16<TI>::N;
+    for (long long m = (long long)blockIdx.x * 256 + threadIdx.x; m < M; m += (long long)gridDim.x * 256) {
+        float o[COUT];
+#pragma unroll
+        for (int k = 0; k < COUT; ++k) o[k] = w[CIN * COUT + k];
+#pragma unroll
+        for (int c0 = 0; c0 < CIN; c0 += VN) {
+            const Vec16<TI> v = ld16(X + m * CIN + c0);
+#pragma unroll
+            for (int e = 0; e < VN; ++e)
+#pragma unroll
+                for (int k = 0; k < COUT; ++k) o[k] += v.get(e) * w[(c0 + e) * COUT + k];
+        }
+#pragma unroll
+        for (int k = 0; k < COUT; ++k) Y[m * COUT + k] = o[k];
+    }
+}
+
+// gx[m, 0..COUT) = sum_k g[m, k] * W[k][.]   (2 logit gradients -> 16 channels, 16-B stores)
+template <typename TO, int CIN, int COUT>
+__global__ __launch_bounds__(256) void head_1x1_bwd_kernel(const float* __restrict__ G, const float* __restrict__ W,
+                                                           TO* __restrict__ Y, long long M, int accumulate) {
+    __shared__ float w[CIN * COUT];
+    if (threadIdx.x < CIN * COUT) w[threadIdx.x] = W[threadIdx.x];
+    __syncthreads();
+    constexpr int VN = Vec16<TO>::N;
+    for (long long m = (long long)blockIdx.x * 256 + threadIdx.x; m < M; m += (long long)gridDim.x * 256) {
+        float g[CIN];
+#pragma unroll
+        for (int k = 0; k < CIN; ++k) g[k] = G[m * CIN + k];
+#pragma unroll
+        for (int c0 = 0; c0 < COUT; c0 += VN) {
+            Vec16<TO> o;
+            if (accumulate) o = ld16(Y + m * COUT + c0);
+#pragma unroll
+            for (int e = 0; e < VN; ++e) {
+                float v = accumulate ? o.get(e) : 0.f;
+#pragma unroll
+                for (int k = 0; k < CIN; ++k) v += g[k] * w[k * COUT + c0 + e];
+                o.set(e, v);
+            }
+            st16(Y + m * COUT + c0, o);
+        }
+    }
 }
 
 // out[map(i)] = sum_p part[p*L + i], i = (t*Cin + ci)*Cout + co, map = t*s_t + ci*s_c + co*s_n
@@ -552,23 +686,56 @@ extern "C" int dycon_pack_tcn(const float* w, float* out, int T, int Cin, int N,
     return DYCON_OK;
 }
 
+// split-K plan: small spatial levels have too few 64-row blocks to fill 256 CUs and a long serial K loop
+struct SplitK { int splits, kc_per_split; };
+static SplitK splitk_plan(int dtype, int mode, int scatter, long long M, int N, int Cin) {
+    const int KC = dtype == DYCON_BF16 ? 32 : 16;
+    const int Tn = mode == DYCON_CONV_K3 ? 27 : mode == DYCON_CONV_K2S2 ? 8 : 1;
+    const int nKC = (Tn * Cin + KC - 1) / KC;
+    const long long wgs = ((M + 63) / 64) * (((N + 15) / 16 + NTB - 1) / NTB);
+    SplitK p{1, nKC};
+    if (scatter || wgs >= 512 || nKC < 16) return p;
+    long long s = (1024 + wgs - 1) / wgs;
+    if (s > nKC / 6) s = nKC / 6;
+    if (s < 2) return p;
+    p.kc_per_split = (int)((nKC + s - 1) / s);
+    p.splits = (nKC + p.kc_per_split - 1) / p.kc_per_split;
+    return p;
+}
+
 template <typename T, int MODE, bool SC>
 static void launch_gemm(const void* x, const void* wf, const float* bias, void* y, int accumulate, int B, int Di, int Hi,
-                        int Wi, int Cin, int N, int Cout, dycon_stream_t stream) {
+                        int Wi, int Cin, int N, int Cout, float* workspace, dycon_stream_t stream) {
     int Do, Ho, Wo;
     row_grid(MODE, Di, Hi, Wi, Do, Ho, Wo);
     const long long M = (long long)B * Do * Ho * Wo;
     const int NT = (N + 15) / 16;
     const int Tn = MODE == DYCON_CONV_K3 ? 27 : MODE == DYCON_CONV_K2S2 ? 8 : 1;
     const int nKC = (Tn * Cin + Frag<T>::KC - 1) / Frag<T>::KC;
-    dim3 grid(cdiv(M, 64), cdiv(NT, NTB));
+    const SplitK sk = splitk_plan(sizeof(T) == 2 ? DYCON_BF16 : DYCON_F32, MODE, SC, M, N, Cin);
+    const bool split = sk.splits > 1 && workspace != nullptr;
+    dim3 grid(cdiv(M, 64), cdiv(NT, NTB), split ? sk.splits : 1);
     conv_gemm_kernel<T, MODE, SC><<<grid, 256, 0, stream>>>((const T*)x, (const T*)wf, bias, (T*)y, B, Di, Hi, Wi, Cin, Do, Ho,
-                                                            Wo, N, Cout, NT, nKC, accumulate);
+                                                            Wo, N, Cout, NT, nKC, accumulate, split ? workspace : nullptr,
+                                                            sk.kc_per_split);
+    if (split) {
+        long long blocks = (M * N + 255) / 256;
+        if (blocks > 2048) blocks = 2048;
+        splitk_finish_kernel<T><<<(int)blocks, 256, 0, stream>>>(workspace, sk.splits, M * N, N, bias, (T*)y, accumulate);
+    }
+}
+
+extern "C" size_t dycon_conv_gemm_workspace(int dtype, int mode, int scatter, int B, int Di, int Hi, int Wi, int Cin, int N) {
+    int Do, Ho, Wo;
+    row_grid(mode, Di, Hi, Wi, Do, Ho, Wo);
+    const long long M = (long long)B * Do * Ho * Wo;
+    const SplitK sk = splitk_plan(dtype, mode, scatter, M, N, Cin);
+    return sk.splits > 1 ? (size_t)sk.splits * M * N * sizeof(float) : 0;
 }
 
 extern "C" int dycon_conv_gemm(const void* x, const void* wfrag, const float* bias, void* y, int dtype, int mode,
                                int scatter, int accumulate, int B, int Di, int Hi, int Wi, int Cin, int N, int Cout,
-                               dycon_stream_t stream) {
+                               float* workspace, size_t ws_bytes, dycon_stream_t stream) {
     DYCON_REQUIRE(x && wfrag && y, "conv_gemm: null pointer");
     DYCON_REQUIRE(B > 0 && Di > 0 && Hi > 0 && Wi > 0 && Cin > 0 && N > 0 && Cout > 0, "conv_gemm: bad shape");
     DYCON_REQUIRE(mode >= 0 && mode <= 2, "conv_gemm: bad mode %d", mode);
@@ -577,11 +744,13 @@ extern "C" int dycon_conv_gemm(const void* x, const void* wfrag, const float* bi
     DYCON_REQUIRE(!scatter || (mode == DYCON_CONV_1X1 && N == 8 * Cout), "conv_gemm: scatter needs mode 1x1 and N == 8*Cout");
     DYCON_REQUIRE(scatter || N == Cout, "conv_gemm: N must equal Cout without scatter");
     DYCON_REQUIRE(mode != DYCON_CONV_K2S2 || (Di % 2 == 0 && Hi % 2 == 0 && Wi % 2 == 0), "conv_gemm: k2s2 needs even dims");
+    // split-K only when the caller provides the slab workspace (NULL -> single pass, same result up to fp32 summation order)
+    float* ws = (workspace && ws_bytes >= dycon_conv_gemm_workspace(dtype, mode, scatter, B, Di, Hi, Wi, Cin, N)) ? workspace : nullptr;
     DYCON_DISPATCH(dtype, {
-        if (scatter) launch_gemm<T, DYCON_CONV_1X1, true>(x, wfrag, bias, y, accumulate, B, Di, Hi, Wi, Cin, N, Cout, stream);
-        else if (mode == DYCON_CONV_K3) launch_gemm<T, DYCON_CONV_K3, false>(x, wfrag, bias, y, accumulate, B, Di, Hi, Wi, Cin, N, Cout, stream);
-        else if (mode == DYCON_CONV_K2S2) launch_gemm<T, DYCON_CONV_K2S2, false>(x, wfrag, bias, y, accumulate, B, Di, Hi, Wi, Cin, N, Cout, stream);
-        else launch_gemm<T, DYCON_CONV_1X1, false>(x, wfrag, bias, y, accumulate, B, Di, Hi, Wi, Cin, N, Cout, stream);
+        if (scatter) launch_gemm<T, DYCON_CONV_1X1, true>(x, wfrag, bias, y, accumulate, B, Di, Hi, Wi, Cin, N, Cout, ws, stream);
+        else if (mode == DYCON_CONV_K3) launch_gemm<T, DYCON_CONV_K3, false>(x, wfrag, bias, y, accumulate, B, Di, Hi, Wi, Cin, N, Cout, ws, stream);
+        else if (mode == DYCON_CONV_K2S2) launch_gemm<T, DYCON_CONV_K2S2, false>(x, wfrag, bias, y, accumulate, B, Di, Hi, Wi, Cin, N, Cout, ws, stream);
+        else launch_gemm<T, DYCON_CONV_1X1, false>(x, wfrag, bias, y, accumulate, B, Di, Hi, Wi, Cin, N, Cout, ws, stream);
     });
     DYCON_LAUNCH_CHECK();
     return DYCON_OK;
@@ -608,6 +777,23 @@ extern "C" int dycon_conv_direct(const void* x, int x_dtype, const float* w_tcn,
     DYCON_REQUIRE(x && w_tcn && y, "conv_direct: null pointer");
     DYCON_REQUIRE(B > 0 && Di > 0 && Hi > 0 && Wi > 0 && Cin > 0 && N > 0, "conv_direct: bad shape");
     DYCON_REQUIRE(mode >= 0 && mode <= 2, "conv_direct: bad mode %d", mode);
+    if (mode == DYCON_CONV_1X1) {   // the 2-class heads: vectorised streaming kernels
+        const long long M = (long long)B * Di * Hi * Wi;
+        long long blocks = (M + 255) / 256;
+        if (blocks > 4096) blocks = 4096;
+        if (Cin == 16 && N == 2 && y_dtype == DYCON_F32 && !accumulate) {
+            if (x_dtype == DYCON_F32) head_1x1_fwd_kernel<float, 16, 2><<<(int)blocks, 256, 0, stream>>>((const float*)x, w_tcn, bias, (float*)y, M);
+            else head_1x1_fwd_kernel<bf16, 16, 2><<<(int)blocks, 256, 0, stream>>>((const bf16*)x, w_tcn, bias, (float*)y, M);
+            DYCON_LAUNCH_CHECK();
+            return DYCON_OK;
+        }
+        if (Cin == 2 && N == 16 && x_dtype == DYCON_F32 && !bias) {
+            if (y_dtype == DYCON_F32) head_1x1_bwd_kernel<float, 2, 16><<<(int)blocks, 256, 0, stream>>>((const float*)x, w_tcn, (float*)y, M, accumulate);
+            else head_1x1_bwd_kernel<bf16, 2, 16><<<(int)blocks, 256, 0, stream>>>((const float*)x, w_tcn, (bf16*)y, M, accumulate);
+            DYCON_LAUNCH_CHECK();
+            return DYCON_OK;
+        }
+    }
     if (x_dtype == DYCON_F32 && y_dtype == DYCON_F32) launch_direct<float, float>(x, w_tcn, bias, y, mode, accumulate, B, Di, Hi, Wi, Cin, N, stream);
     else if (x_dtype == DYCON_BF16 && y_dtype == DYCON_F32) launch_direct<bf16, float>(x, w_tcn, bias, y, mode, accumulate, B, Di, Hi, Wi, Cin, N, stream);
     else if (x_dtype == DYCON_F32 && y_dtype == DYCON_BF16) launch_direct<float, bf16>(x, w_tcn, bias, y, mode, accumulate, B, Di, Hi, Wi, Cin, N, stream);
@@ -659,7 +845,7 @@ static WgradK3Plan wgrad_k3_plan(int B, int D, int H, int W, int Cin, int Cout) 
     p.nTiles = B * p.tilesZ * p.tilesY * p.tilesX;
     p.NT = Cout >= 64 ? 4 : Cout / 16;
     p.nCoBlk = cdiv(Cout, 16 * p.NT);
-    p.gx = (Cin / 16) * p.nCoBlk;
+    p.gx = ((Cin + 15) / 16) * p.nCoBlk;
     const long long L = 27LL * Cin * Cout;
     long long s = 2048 / p.gx;
     const long long cap = (24LL << 20) / (4 * L);
@@ -670,7 +856,7 @@ static WgradK3Plan wgrad_k3_plan(int B, int D, int H, int W, int Cin, int Cout) 
     return p;
 }
 static bool wgrad_k3_ok(int mode, int Cin, int Cout) {
-    return mode == DYCON_CONV_K3 && Cin % 16 == 0 && Cout % 16 == 0 && (Cout == 16 || Cout == 32 || Cout % 64 == 0);
+    return mode == DYCON_CONV_K3 && (Cin % 16 == 0 || Cin == 1) && Cout % 16 == 0 && (Cout == 16 || Cout == 32 || Cout % 64 == 0);
 }
 
 extern "C" size_t dycon_conv_wgrad_workspace(int mode, int B, int Di, int Hi, int Wi, int Cin, int Cout) {
@@ -724,11 +910,12 @@ extern "C" int dycon_conv_wgrad(const void* x, int x_dtype, const void* gy, int 
         const WgradK3Plan k = wgrad_k3_plan(B, Di, Hi, Wi, Cin, Cout);
         float* bpart = dbias ? workspace + (size_t)k.splits * p.L : nullptr;
         dim3 grid(k.gx, k.splits);
-#define DYCON_WK3(NTV) \
-    wgrad_k3_bf16_kernel<NTV><<<grid, 256, 0, stream>>>((const bf16*)x, (const bf16*)gy, workspace, bpart, B, Di, Hi, Wi, Cin, Cout, k.nCoBlk, k.nTiles, k.tilesZ, k.tilesY, k.tilesX)
-        if (k.NT == 1) DYCON_WK3(1);
-        else if (k.NT == 2) DYCON_WK3(2);
-        else DYCON_WK3(4);
+#define DYCON_WK3(NTV, C1) \
+    wgrad_k3_bf16_kernel<NTV, C1><<<grid, 256, 0, stream>>>((const bf16*)x, (const bf16*)gy, workspace, bpart, B, Di, Hi, Wi, Cin, Cout, k.nCoBlk, k.nTiles, k.tilesZ, k.tilesY, k.tilesX)
+        if (Cin == 1) { if (k.NT == 1) DYCON_WK3(1, true); else if (k.NT == 2) DYCON_WK3(2, true); else DYCON_WK3(4, true); }
+        else if (k.NT == 1) DYCON_WK3(1, false);
+        else if (k.NT == 2) DYCON_WK3(2, false);
+        else DYCON_WK3(4, false);
 #undef DYCON_WK3
         DYCON_LAUNCH_CHECK();
         reduce_partials_kernel<<<cdiv(p.L, 32), 256, 0, stream>>>(workspace, k.splits, p.L, dw, Cin, Cout, s_t, s_c, s_n);
@@ -736,6 +923,21 @@ extern "C" int dycon_conv_wgrad(const void* x, int x_dtype, const void* gy, int 
         if (dbias) {
             reduce_partials_kernel<<<cdiv(Cout, 32), 256, 0, stream>>>(bpart, k.splits, Cout, dbias, 1, Cout, 0, 0, 1);
             DYCON_LAUNCH_CHECK();
+        }
+        return DYCON_OK;
+    }
+    if (mode == DYCON_CONV_1X1 && Cin == 16 && Cout == 2 && g_dtype == DYCON_F32) {
+        const long long M = (long long)B * Di * Hi * Wi;
+        int blocks = p.splits;                      // partial rows available in the workspace (>= M/1024)
+        if (blocks > 1024) blocks = 1024;
+        if (x_dtype == DYCON_F32) wgrad_1x1_skinny_kernel<float, float, 16, 2><<<blocks, 256, 0, stream>>>((const float*)x, (const float*)gy, workspace, M);
+        else wgrad_1x1_skinny_kernel<bf16, float, 16, 2><<<blocks, 256, 0, stream>>>((const bf16*)x, (const float*)gy, workspace, M);
+        DYCON_LAUNCH_CHECK();
+        reduce_partials_kernel<<<cdiv(p.L, 32), 256, 0, stream>>>(workspace, blocks, p.L, dw, Cin, Cout, s_t, s_c, s_n);
+        DYCON_LAUNCH_CHECK();
+        if (dbias) {
+            float* cws = workspace + (size_t)p.splits * p.L;
+            return dycon_colsum(gy, g_dtype, dbias, M, Cout, cws, dycon_colsum_workspace(M, Cout), stream);
         }
         return DYCON_OK;
     }

@@ -222,20 +222,53 @@ __global__ void mask_pool_kernel(const void* __restrict__ labels, int label_byte
 // =================================================================================================
 constexpr int FT = 64;  // tile edge
 
-template <typename T>
-__device__ __forceinline__ void stage_rows(float* __restrict__ dst, int stride, int Dp, const T* __restrict__ src, int row0,
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef short s16x4_t __attribute__((ext_vector_type(4)));
+typedef short s16x8_t __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) s16x4_t* lds_s16x4_ptr_t;
+
+// Tile geometry per storage type.  fp32 (parity mode): fp32 rows in LDS, v_mfma_f32_16x16x4_f32 (exact fp32 products).
+// bf16: bf16 rows in LDS, v_mfma_f32_16x16x32_bf16 (exact products of the stored values, fp32 accumulate) -- 8x fewer
+// matrix-core cycles and half the LDS bytes; the epilogue (exp/log chain) is fp32 in both.
+template <typename T> struct FeclTile;
+template <> struct FeclTile<float> {
+    typedef float E;
+    static constexpr int KS = 16, PAD = 4, TPAD = 4;
+};
+template <> struct FeclTile<bf16> {
+    typedef unsigned short E;
+    static constexpr int KS = 32, PAD = 8, TPAD = 8;
+};
+
+__device__ __forceinline__ void stage_rows(float* __restrict__ dst, int stride, int Dp, const float* __restrict__ src, int row0,
                                            int N, int Dm) {
-    // dst[r][k] = src[row0 + r][k] (fp32), zero for rows >= N and k >= Dm
     for (int e = threadIdx.x; e < FT * Dp; e += 256) {
         const int r = e / Dp, k = e - r * Dp;
         float v = 0.f;
-        if (row0 + r < N && k < Dm) v = ldf(src + (long long)(row0 + r) * Dm + k);
+        if (row0 + r < N && k < Dm) v = src[(long long)(row0 + r) * Dm + k];
         dst[r * stride + k] = v;
     }
 }
+__device__ __forceinline__ void stage_rows(unsigned short* __restrict__ dst, int stride, int Dp, const bf16* __restrict__ src,
+                                           int row0, int N, int Dm) {
+    const unsigned short* s16 = reinterpret_cast<const unsigned short*>(src);
+    if ((Dm & 7) == 0) {   // 16-byte pieces
+        const int ppr = Dp >> 3;
+        for (int e = threadIdx.x; e < FT * ppr; e += 256) {
+            const int r = e / ppr, k = (e - r * ppr) << 3;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (row0 + r < N && k < Dm) v = *reinterpret_cast<const uint4*>(s16 + (long long)(row0 + r) * Dm + k);
+            *reinterpret_cast<uint4*>(dst + r * stride + k) = v;
+        }
+    } else {
+        for (int e = threadIdx.x; e < FT * Dp; e += 256) {
+            const int r = e / Dp, k = e - r * Dp;
+            dst[r * stride + k] = (row0 + r < N && k < Dm) ? s16[(long long)(row0 + r) * Dm + k] : (unsigned short)0;
+        }
+    }
+}
 
-// S tile for this wave: rows 16*wave..+15 of Fi against the 64 rows of Fj.  K order inside a 16-chunk is
-// k = 16q + 4*kg + e so that each lane fetches its 4 consecutive k with one ds_read_b128.
+// S tile for this wave: rows 16*wave..+15 of Fi against the 64 rows of Fj (both row-major, K contiguous).
 __device__ __forceinline__ void gram_tile(const float* __restrict__ Fi, const float* __restrict__ Fj, int stride, int nq,
                                           int wave, int lane, f32x4 acc[4]) {
     const int r = lane & 15, kg = lane >> 4;
@@ -243,7 +276,7 @@ __device__ __forceinline__ void gram_tile(const float* __restrict__ Fi, const fl
     for (int j = 0; j < 4; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
     const float* ap = Fi + (16 * wave + r) * stride + 4 * kg;
     const float* bp = Fj + r * stride + 4 * kg;
-    for (int q = 0; q < nq; ++q) {
+    for (int q = 0; q < nq; ++q) {   // K order inside a 16-chunk: k = 16q + 4*kg + e  (one ds_read_b128 per lane)
         const float4 a = *reinterpret_cast<const float4*>(ap + 16 * q);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -255,6 +288,58 @@ __device__ __forceinline__ void gram_tile(const float* __restrict__ Fi, const fl
         }
     }
 }
+__device__ __forceinline__ void gram_tile(const unsigned short* __restrict__ Fi, const unsigned short* __restrict__ Fj, int stride,
+                                          int nq, int wave, int lane, f32x4 acc[4]) {
+    const int r = lane & 15, kg = lane >> 4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const unsigned short* ap = Fi + (16 * wave + r) * stride + 8 * kg;
+    const unsigned short* bp = Fj + r * stride + 8 * kg;
+    for (int q = 0; q < nq; ++q) {   // k = 32q + 8*kg + e
+        const bf16x8_t a = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(ap + 32 * q));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bf16x8_t b = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(bp + 16 * j * stride + 32 * q));
+            acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[j], 0, 0, 0);
+        }
+    }
+}
+
+// gf[16 rows of this wave][16*t + .] += W[rows][64] * Fj[64][.]   (W = the per-pair weight tile, A operand; Fj = B operand)
+template <int MAXNT>
+__device__ __forceinline__ void weight_gemm(const float* __restrict__ Tt, int tstride, const float* __restrict__ Fj, int stride,
+                                            int ntile, int wave, int lane, f32x4 gacc[MAXNT]) {
+    const int r = lane & 15, kg = lane >> 4;
+    for (int s = 0; s < FT / 4; ++s) {
+        const float a = Tt[(16 * wave + r) * tstride + 4 * s + kg];
+        const float* bp = Fj + (4 * s + kg) * stride + r;
+#pragma unroll
+        for (int t = 0; t < MAXNT; ++t)
+            if (t < ntile) gacc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bp[16 * t], gacc[t], 0, 0, 0);
+    }
+}
+template <int MAXNT>
+__device__ __forceinline__ void weight_gemm(const unsigned short* __restrict__ Tt, int tstride, const unsigned short* __restrict__ Fj,
+                                            int stride, int ntile, int wave, int lane, f32x4 gacc[MAXNT]) {
+    const int r = lane & 15, kg = lane >> 4, q = r >> 2, p = r & 3;
+#pragma unroll
+    for (int s = 0; s < FT / 32; ++s) {
+        const bf16x8_t a = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(Tt + (16 * wave + r) * tstride + 32 * s + 8 * kg));
+        // B[k = pair column j][col = feature d] = Fj[j][d]: 8 rows of Fj at one column -> transposed LDS read
+        const unsigned short* b0 = Fj + (32 * s + 8 * kg + q) * stride + 4 * p;
+#pragma unroll
+        for (int t = 0; t < MAXNT; ++t) {
+            if (t < ntile) {
+                const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr_t)(b0 + 16 * t));
+                const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr_t)(b0 + 16 * t + 4 * stride));
+                const s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                gacc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, __builtin_bit_cast(bf16x8_t, v), gacc[t], 0, 0, 0);
+            }
+        }
+    }
+}
+__device__ __forceinline__ void put_weight(float* Tt, int idx, float v) { Tt[idx] = v; }
+__device__ __forceinline__ void put_weight(unsigned short* Tt, int idx, float v) { Tt[idx] = f32_to_bf16_bits(v); }
 
 // sum / max over the 16 lanes that share a row group (lane bits 0..3)
 __device__ __forceinline__ float row16_sum(float v) {
@@ -286,12 +371,15 @@ __global__ __launch_bounds__(256) void fecl_kernel(const T* __restrict__ F, cons
                                                    float tau, float gamma, int focal, float thr, float* __restrict__ ws,
                                                    double* __restrict__ out, const float* __restrict__ coef, float lambda_cross,
                                                    T* __restrict__ GF, int Btot) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int Dp = (Dm + 15) / 16 * 16, stride = Dp + 4, nq = Dp / 16;
-    float* Fi = lds;
-    float* Fj = lds + FT * stride;
-    float* Tt = Fj + FT * stride;                      // PASS 4 only: 64 x (64+4) weight tile
-    const int tstride = FT + 4;
+    typedef typename FeclTile<T>::E E;
+    constexpr int KS = FeclTile<T>::KS;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    E* lds = reinterpret_cast<E*>(lds_raw);
+    const int Dp = (Dm + KS - 1) / KS * KS, stride = Dp + FeclTile<T>::PAD, nq = Dp / KS;
+    E* Fi = lds;
+    E* Fj = lds + FT * stride;
+    E* Tt = Fj + FT * stride;                          // PASS 4 only: 64 x 64 pair-weight tile
+    constexpr int tstride = FT + FeclTile<T>::TPAD;
     const int b = blockIdx.y, i0 = blockIdx.x * FT;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 15, kg = lane >> 4;
@@ -327,6 +415,7 @@ __global__ __launch_bounds__(256) void fecl_kernel(const T* __restrict__ F, cons
 
     // PASS 4: persistent output tile  gf[16 rows of this wave][Dp], as Dp/16 accumulators
     constexpr int MAXNT = 16;   // Dm <= 256
+    const int ntile = (Dm + 15) / 16;
     f32x4 gacc[MAXNT];
     if (PASS == 4) {
 #pragma unroll
@@ -387,7 +476,7 @@ __global__ __launch_bounds__(256) void fecl_kernel(const T* __restrict__ F, cons
                     }
                 }
             }
-        } else {  // PASS 4: T_ij = dL_ij + dL_ji  -> LDS
+        } else {  // PASS 4: W_ij = dL_ij + dL_ji  -> LDS
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int gj = j0 + 16 * j + r;
@@ -413,18 +502,11 @@ __global__ __launch_bounds__(256) void fecl_kernel(const T* __restrict__ F, cons
                         }
                         tv *= stud_scale / tau;
                     }
-                    Tt[(16 * wave + 4 * kg + i) * tstride + 16 * j + r] = tv;
+                    put_weight(Tt, (16 * wave + 4 * kg + i) * tstride + 16 * j + r, tv);
                 }
             }
             __syncthreads();
-            // gf[rows of wave][d] += T[rows][64] * Fj[64][d]
-            for (int s = 0; s < FT / 4; ++s) {
-                const float a = Tt[(16 * wave + r) * tstride + 4 * s + kg];
-                const float* bp = Fj + (4 * s + kg) * stride + r;
-#pragma unroll
-                for (int t = 0; t < MAXNT; ++t)
-                    if (t < nq) gacc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bp[16 * t], gacc[t], 0, 0, 0);
-            }
+            weight_gemm<MAXNT>(Tt, tstride, Fj, stride, ntile, wave, lane, gacc);
         }
 
         if ((PASS == 3 || PASS == 4) && Tb) {   // cross branch against the teacher rows of this column tile
@@ -444,19 +526,13 @@ __global__ __launch_bounds__(256) void fecl_kernel(const T* __restrict__ F, cons
                     if (PASS == 3) {
                         if (hard) { cnum += -logf(1.f - sx + 1e-18f); ccnt += 1.f; }
                     } else {
-                        Tt[(16 * wave + 4 * kg + i) * tstride + 16 * j + r] = hard ? cross_scale / (1.f - sx + 1e-18f) : 0.f;
+                        put_weight(Tt, (16 * wave + 4 * kg + i) * tstride + 16 * j + r, hard ? cross_scale / (1.f - sx + 1e-18f) : 0.f);
                     }
                 }
             }
             if (PASS == 4) {
                 __syncthreads();
-                for (int s = 0; s < FT / 4; ++s) {
-                    const float a = Tt[(16 * wave + r) * tstride + 4 * s + kg];
-                    const float* bp = Fj + (4 * s + kg) * stride + r;
-#pragma unroll
-                    for (int t = 0; t < MAXNT; ++t)
-                        if (t < nq) gacc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bp[16 * t], gacc[t], 0, 0, 0);
-                }
+                weight_gemm<MAXNT>(Tt, tstride, Fj, stride, ntile, wave, lane, gacc);
             }
         }
     }
@@ -487,7 +563,8 @@ __global__ __launch_bounds__(256) void fecl_kernel(const T* __restrict__ F, cons
                 lsum += ph * kap;
             }
         }
-        float* red = lds;   // staging buffers are dead; keep ALL LDS in the one dynamic array (16-B aligned base)
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(lds_raw);   // staging buffers are dead; ALL LDS stays in the one dynamic array
         const float bs = block_sum(lsum, red), bn = block_sum(cnum, red), bc = block_sum(ccnt, red);
         if (threadIdx.x == 0) {
             atomicAdd(&out[0], (double)bs);
@@ -497,7 +574,7 @@ __global__ __launch_bounds__(256) void fecl_kernel(const T* __restrict__ F, cons
         T* gb = GF + (long long)b * N * Dm;
 #pragma unroll
         for (int t = 0; t < MAXNT; ++t) {
-            if (t >= nq) continue;
+            if (t >= ntile) continue;
             const int d = 16 * t + r;
             if (d >= Dm) continue;
 #pragma unroll
@@ -592,16 +669,18 @@ extern "C" int dycon_mask_pool(const void* labels, int label_bytes, float* mask,
 
 extern "C" size_t dycon_fecl_workspace(int B, int N) { return (size_t)5 * B * N * sizeof(float); }
 
-static size_t fecl_lds_bytes(int Dm, bool grad) {
-    const int Dp = (Dm + 15) / 16 * 16, stride = Dp + 4;
-    return ((size_t)2 * FT * stride + (grad ? FT * (FT + 4) : 0)) * sizeof(float);
+template <typename T> static size_t fecl_lds_bytes(int Dm, bool grad) {
+    typedef FeclTile<T> G;
+    const int Dp = (Dm + G::KS - 1) / G::KS * G::KS, stride = Dp + G::PAD;
+    size_t n = ((size_t)2 * FT * stride + (grad ? FT * (FT + G::TPAD) : 0)) * sizeof(typename G::E);
+    return n < 256 ? 256 : n;   // the pass-3 block reduction borrows the first floats
 }
 
 template <typename T, int PASS>
 static int fecl_launch(const void* feat, const void* teacher, const float* mask, const float* gamb, int B, int N, int Dm,
                        float tau, float gamma, int focal, float thr, float* ws, double* out, const float* coef, float lambda_cross,
                        void* gf, dycon_stream_t stream) {
-    const size_t lds = fecl_lds_bytes(Dm, PASS == 4);
+    const size_t lds = fecl_lds_bytes<T>(Dm, PASS == 4);
     // > 64 KiB of dynamic LDS needs the opt-in attribute (idempotent, no sync, capture-safe)
     if (hipFuncSetAttribute((const void*)fecl_kernel<T, PASS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
         dycon_set_error("fecl: cannot reserve %zu bytes of LDS", lds);

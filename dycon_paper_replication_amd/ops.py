@@ -113,10 +113,12 @@ def conv_gemm(x, wfrag, bias, mode, N, Cout, scatter=False, out=None, accumulate
         out = torch.empty(shape, dtype=x.dtype, device=x.device)
     taps = {CONV_K3: 27, CONV_K2S2: 8, CONV_1X1: 1}[mode]
     rows = out.numel() // Cout if not scatter else x.numel() // Cin
+    nws = query("dycon_conv_gemm_workspace", dt(x), mode, int(scatter), B, D, H, W, Cin, N)
+    ws = _ws(nws, x) if nws else None
     with _Region("conv_gemm", (x.numel() + out.numel() * (2 if accumulate else 1)) * _es(x) + taps * Cin * N * _es(x),
                  2 * rows * taps * Cin * N):
         call("dycon_conv_gemm", _p(x), _p(wfrag), _p(bias), _p(out), dt(x), mode, int(scatter), int(accumulate),
-             B, D, H, W, Cin, N, Cout, _s())
+             B, D, H, W, Cin, N, Cout, _p(ws), nws, _s())
     return out
 
 

@@ -63,10 +63,14 @@ int dycon_pack_tcn(const float* w, float* out, int T, int Cin, int N, int N0, lo
  *   accumulate=1: y += result (used to sum the two gradient paths into a skip tensor,
  *              VNet.py:210-222 / networks/utils.py:276).
  * Replaces F.conv3d / F.conv_transpose3d forward and their data-gradients.
- * Needs Cin % 8 == 0 (bf16) or Cin % 4 == 0 (f32), N % 16 == 0; otherwise use *_direct. */
+ * Needs Cin % 8 == 0 (bf16) or Cin % 4 == 0 (f32), N % 16 == 0; otherwise use *_direct.
+ * workspace (optional, dycon_conv_gemm_workspace() bytes): enables split-K for the small spatial
+ * levels (6^3, 12^3), whose few row blocks cannot fill 256 CUs: per-split fp32 slabs + ordered finish. */
+size_t dycon_conv_gemm_workspace(int dtype, int mode, int scatter, int B, int Di, int Hi, int Wi,
+                                 int Cin, int N);
 int dycon_conv_gemm(const void* x, const void* wfrag, const float* bias, void* y, int dtype,
                     int mode, int scatter, int accumulate, int B, int Di, int Hi, int Wi, int Cin,
-                    int N, int Cout, dycon_stream_t stream);
+                    int N, int Cout, float* workspace, size_t ws_bytes, dycon_stream_t stream);
 /* skinny channels (first layer 1->16, 1x1 heads 16->2 and their data-gradient 2->16):
  * w_tcn is fp32 [T][Cin][N]; x and y may have different dtypes (bf16 features, fp32 logits). */
 int dycon_conv_direct(const void* x, int x_dtype, const float* w_tcn, const float* bias, void* y,
