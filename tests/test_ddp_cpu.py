@@ -1,0 +1,133 @@
+"""CPU, world size 2 over gloo: the data-parallel exchange of DESIGN.md section 6.
+
+The HIP kernels cannot run here; what is checked is the ARITHMETIC of the scheme the trainer uses:
+shard [labelled | unlabelled] per rank, all-reduce the Dice / FeCL-cross accumulators, differentiate the
+global-ratio terms w.r.t. local voxels pre-scaled by `world`, average the gradient arena -- and that the
+result equals the single-process gradient of the reference's global-batch loss (oracle functions)."""
+import os
+import tempfile
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+import torch.nn.functional as F
+
+from oracle import losses as OL
+
+WORLD = 2
+
+
+def _tiny_net(x, w_seg, w_feat):
+    logits = F.conv3d(x, w_seg, padding=1)
+    feats = F.conv3d(F.avg_pool3d(x, 4), w_feat)
+    return logits, feats
+
+
+def _data():
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(4, 1, 8, 8, 8, generator=g)                     # global batch: [lab0, lab1 | unl0, unl1]
+    lab = (torch.rand(4, 8, 8, 8, generator=g) > 0.6).long()
+    xt = x + 0.1 * torch.randn(4, 1, 8, 8, 8, generator=g)
+    w_seg = 0.3 * torch.randn(2, 1, 3, 3, 3, generator=g)
+    w_feat = torch.randn(16, 1, 1, 1, 1, generator=g)
+    w_seg_t = w_seg + 0.05 * torch.randn(2, 1, 3, 3, 3, generator=g)
+    w_feat_t = w_feat + 0.3 * torch.randn(16, 1, 1, 1, 1, generator=g)
+    return x, lab, xt, w_seg, w_feat, w_seg_t, w_feat_t
+
+
+CW, UW, BETA, THR = 0.07, 0.5, 2.0, 0.05
+
+
+def _global_loss(x, lab, xt, w_seg, w_feat, w_seg_t, w_feat_t, LB):
+    s_logits, s_feat = _tiny_net(x, w_seg, w_feat)
+    with torch.no_grad():
+        t_logits, t_feat = _tiny_net(xt, w_seg_t, w_feat_t)
+    sp, tp = F.softmax(s_logits, 1), F.softmax(t_logits, 1)
+    ce = F.cross_entropy(s_logits[:LB], lab[:LB])
+    dice = OL.dice_loss(sp[:LB, 1], lab[:LB] == 1)
+    cons = OL.softmax_mse(sp[LB:], tp[LB:]).mean()
+    mask = OL.contrast_mask(lab, 4)
+    # epoch chosen so that threshold_rampup(...) == THR is not needed: pass the threshold through rampup_epochs=0 path
+    f = _fecl_with_thr(OL.embed(s_feat), mask, OL.embed(t_feat), THR)
+    u = OL.uncl(s_logits, t_logits, BETA)
+    return ce + dice + CW * cons + UW * (f + u)
+
+
+def _fecl_parts(feat, mask, teacher, thr):
+    """per-sample student means, cross numerator and count (the accumulators dycon_fecl_fwd produces)"""
+    B, N, _ = feat.shape
+    m = mask.reshape(B, N)
+    eye = torch.eye(N)
+    stud, num, cnt = [], feat.new_zeros(()), feat.new_zeros(())
+    for b in range(B):
+        same = (m[b][:, None] == m[b][None, :]).float()
+        L = (feat[b] @ feat[b].t()) / 0.6 * (1 - eye)
+        L = L - L.max(0, keepdim=True)[0].detach()
+        E = torch.exp(L)
+        P = E / (E + (E * (1 - same)).sum(-1, keepdim=True) + 1e-18)
+        ell = -torch.log(P + 1e-18) * same * (1 - eye) * torch.where(same.bool(), (1 - P) ** 2, torch.ones_like(P))
+        stud.append((ell.sum(-1) / (same.sum(-1) - 1 + 1e-18)).sum())
+        S = feat[b] @ teacher[b].t()
+        hard = ((1 - same).bool() & (S > thr)).float()
+        num = num + (-torch.log(1 - S + 1e-18) * hard).sum()
+        cnt = cnt + hard.sum()
+    return torch.stack(stud).sum(), num, cnt, B * N
+
+
+def _fecl_with_thr(feat, mask, teacher, thr):
+    s, num, cnt, rows = _fecl_parts(feat, mask, teacher, thr)
+    return s / rows + num / (cnt + 1e-18)
+
+
+def _worker(rank, init_file, out_file):
+    dist.init_process_group("gloo", init_method=f"file://{init_file}", rank=rank, world_size=WORLD)
+    x, lab, xt, w_seg, w_feat, w_seg_t, w_feat_t = _data()
+    idx = [rank, 2 + rank]                                            # one labelled + one unlabelled sample per rank
+    xl, ll, xtl = x[idx], lab[idx], xt[idx]
+    w_seg = w_seg.clone().requires_grad_(True)
+    w_feat = w_feat.clone().requires_grad_(True)
+    s_logits, s_feat = _tiny_net(xl, w_seg, w_feat)
+    with torch.no_grad():
+        t_logits, t_feat = _tiny_net(xtl, w_seg_t, w_feat_t)
+    sp, tp = F.softmax(s_logits, 1), F.softmax(t_logits, 1)
+    LB = 1
+    # ---- local accumulators, then the two small all-reduces
+    t1 = (ll[:LB] == 1).float()
+    I, Z, Y = (sp[:LB, 1] * t1).sum(), (sp[:LB, 1] ** 2).sum(), (t1 * t1).sum()
+    stud, num, cnt, rows = _fecl_parts(OL.embed(s_feat), OL.contrast_mask(ll, 4), OL.embed(t_feat), THR)
+    sums = torch.stack([I, Z, Y, num, cnt]).detach().double()
+    dist.all_reduce(sums)
+    Ig, Zg, Yg, numg, cntg = [v.float() for v in sums]
+    # ---- local objective whose gradient is what the kernels produce: global ratios, other ranks' parts constant,
+    #      pre-scaled by world because the arena is AVERAGED afterwards
+    dice_loc = 1 - (2 * (I + (Ig - I.detach())) + 1e-5) / ((Z + (Zg - Z.detach())) + Yg + 1e-5)
+    cross_loc = (num + (numg - num.detach())) / (cntg + 1e-18)
+    ce = F.cross_entropy(s_logits[:LB], ll[:LB])
+    cons = OL.softmax_mse(sp[LB:], tp[LB:]).mean()
+    u = OL.uncl(s_logits, t_logits, BETA)
+    local = ce + WORLD * dice_loc + CW * cons + UW * (stud / rows + WORLD * cross_loc + u)
+    gs, gf = torch.autograd.grad(local, [w_seg, w_feat])
+    flat = torch.cat([gs.reshape(-1), gf.reshape(-1)])
+    dist.all_reduce(flat)                                             # the gradient-arena all-reduce (sum) ...
+    flat /= WORLD                                                     # ... and the 1/world folded into the SGD kernel
+    if rank == 0:
+        # reported loss value is identical on every rank: global sums -> finalize
+        loss_val = float(ce.detach())  # placeholder so the file has both; value check is done on the gradient
+        torch.save({"grad": flat, "loss_local_ce": loss_val}, out_file)
+    dist.destroy_process_group()
+
+
+def test_ddp_exchange_equals_global_batch_gradient():
+    x, lab, xt, w_seg, w_feat, w_seg_t, w_feat_t = _data()
+    ws = w_seg.clone().requires_grad_(True)
+    wf = w_feat.clone().requires_grad_(True)
+    ref = _global_loss(x, lab, xt, ws, wf, w_seg_t, w_feat_t, LB=2)
+    gs, gf = torch.autograd.grad(ref, [ws, wf])
+    ref_flat = torch.cat([gs.reshape(-1), gf.reshape(-1)])
+    with tempfile.TemporaryDirectory() as d:
+        init_file, out_file = os.path.join(d, "init"), os.path.join(d, "out.pt")
+        mp.spawn(_worker, args=(init_file, out_file), nprocs=WORLD, join=True)
+        got = torch.load(out_file)["grad"]
+    np.testing.assert_allclose(got.numpy(), ref_flat.numpy(), rtol=1e-4, atol=1e-6)
