@@ -202,6 +202,113 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const T* __restrict__ X,
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// k=3 convolution with an LDS-staged halo tile (bf16): the large spatial levels.
+//
+// One workgroup = a 4x8x8 block of output voxels (halo 6x10x10) x up to 64 output channels.  The input
+// channels are walked in chunks of CK (16 or 32): the chunk's halo tile is staged once (16-byte loads, zero
+// padding resolved at staging time), then all 27 taps read their A fragments from LDS with one
+// ds_read_b128 per 16x16 tile -- every input byte comes from HBM/L2 once per tile instead of 27 times.
+// B fragments (pre-packed, shared by every workgroup) stream from L1/L2.
+//   CK = 32: voxel rows padded to 80 B so the 8 x-neighbours of a fragment fall in 8 distinct 16-B bank
+//            slots; CK = 16: 32-B rows (8 voxels = one 256-B bank row).
+//   wave layout WM x WN over (16 m-tiles) x (NTW n-tiles): 4x1 for Cout <= 32, 2x2 for 64-wide blocks.
+// ------------------------------------------------------------------------------------------------
+constexpr int CL_TZ = 4, CL_TY = 8, CL_TX = 8;
+constexpr int CL_HZ = CL_TZ + 2, CL_HY = CL_TY + 2, CL_HX = CL_TX + 2;
+constexpr int CL_NH = CL_HZ * CL_HY * CL_HX;     // 600 halo voxels
+constexpr int CL_NV = CL_TZ * CL_TY * CL_TX;     // 256 voxels = 16 m-tiles
+
+template <int CK, int NTB, int WM>
+__global__ __launch_bounds__(256) void conv_k3_lds_kernel(const bf16* __restrict__ X, const bf16* __restrict__ Wf,
+                                                          const float* __restrict__ bias, bf16* __restrict__ Y, int B, int D, int H,
+                                                          int W, int Cin, int Cout, int NT, int tilesZ, int tilesY, int tilesX,
+                                                          int accumulate) {
+    constexpr int WN = 4 / WM;                 // waves along N
+    constexpr int MTW = 16 / WM;               // m-tiles per wave
+    constexpr int NTW = NTB / WN;              // n-tiles per wave
+    constexpr int VS = CK == 32 ? 40 : 16;     // LDS voxel stride in elements (80 B / 32 B)
+    __shared__ __attribute__((aligned(16))) unsigned short Xh[CL_NH * VS];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 15, kg = lane >> 4;
+    const int wm = wave / WN, wn = wave % WN;
+    int tile = blockIdx.x;
+    const int tx = tile % tilesX; tile /= tilesX;
+    const int ty = tile % tilesY; tile /= tilesY;
+    const int tz = tile % tilesZ;
+    const int b = tile / tilesZ;
+    const int z0 = tz * CL_TZ, y0 = ty * CL_TY, x0 = tx * CL_TX;
+    const int nt0 = blockIdx.y * NTB + wn * NTW;
+
+    f32x4 acc[MTW][NTW];
+#pragma unroll
+    for (int m = 0; m < MTW; ++m)
+#pragma unroll
+        for (int j = 0; j < NTW; ++j) acc[m][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // LDS element offset of this lane's voxel (tap (0,0,0) corner of the halo) for each of its m-tiles
+    int vbase[MTW];
+#pragma unroll
+    for (int m = 0; m < MTW; ++m) {
+        const int v = (wm * MTW + m) * 16 + r;                 // voxel index inside the tile: (z, y, x) = (v/64, (v/8)%8, v%8)
+        vbase[m] = (((v >> 6) * CL_HY + ((v >> 3) & 7)) * CL_HX + (v & 7)) * VS;
+    }
+    const int nChunks = Cin / CK;
+    constexpr int NKS = CK == 32 ? 27 : 14;                    // MFMA k-steps (32 wide) per chunk
+    for (int ch = 0; ch < nChunks; ++ch) {
+        __syncthreads();
+        // ---- stage the halo tile of channels [ch*CK, ch*CK + CK)
+        constexpr int PPV = CK / 8;                            // 16-byte pieces per voxel
+        for (int e = threadIdx.x; e < CL_NH * PPV; e += 256) {
+            const int hv = e / PPV, pc = e % PPV;
+            const int hx = hv % CL_HX, hy = (hv / CL_HX) % CL_HY, hz = hv / (CL_HX * CL_HY);
+            const int z = z0 + hz - 1, y = y0 + hy - 1, x = x0 + hx - 1;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if ((unsigned)z < (unsigned)D && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W)
+                v = *reinterpret_cast<const uint4*>(X + ((((long long)b * D + z) * H + y) * W + x) * Cin + ch * CK + 8 * pc);
+            *reinterpret_cast<uint4*>(Xh + hv * VS + 8 * pc) = v;
+        }
+        __syncthreads();
+#pragma unroll 3
+        for (int ks = 0; ks < NKS; ++ks) {
+            int t, coff;
+            if (CK == 32) { t = ks; coff = 8 * kg; }
+            else { t = 2 * ks + (kg >> 1); coff = 8 * (kg & 1); if (t > 26) t = 26; }   // tap 27 is padding: its packed weights are 0
+            const int toff = ((t / 9) * CL_HY * CL_HX + ((t / 3) % 3) * CL_HX + (t % 3)) * VS + coff;
+            // flattened-K chunk index of this k-step in the packed weights (K = tap*Cin + channel, 32 per chunk)
+            const int kc = CK == 32 ? ks * nChunks + ch : ks;
+            bf16x8 bfr[NTW];
+#pragma unroll
+            for (int j = 0; j < NTW; ++j)
+                bfr[j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(Wf + (((long long)kc * NT + nt0 + j) * 64 + lane) * 8));
+#pragma unroll
+            for (int m = 0; m < MTW; ++m) {
+                const bf16x8 afr = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(Xh + vbase[m] + toff));
+#pragma unroll
+                for (int j = 0; j < NTW; ++j) acc[m][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr, bfr[j], acc[m][j], 0, 0, 0);
+            }
+        }
+    }
+    // ---- epilogue: D tile row = 4*kg + i (voxel), col = r (channel)
+#pragma unroll
+    for (int m = 0; m < MTW; ++m) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int v = (wm * MTW + m) * 16 + 4 * kg + i;
+            const int z = z0 + (v >> 6), y = y0 + ((v >> 3) & 7), x = x0 + (v & 7);
+            if (z >= D || y >= H || x >= W) continue;
+            bf16* yp = Y + ((((long long)b * D + z) * H + y) * W + x) * Cout;
+#pragma unroll
+            for (int j = 0; j < NTW; ++j) {
+                const int n = (nt0 + j) * 16 + r;
+                float val = acc[m][j][i] + (bias ? bias[n] : 0.f);
+                if (accumulate) val += __bfloat162float(yp[n]);
+                yp[n] = __float2bfloat16(val);
+            }
+        }
+    }
+}
+
 // y[m, n] (+)= bias[n] + sum_z slab[z][m][n]   (ordered: deterministic)
 template <typename T>
 __global__ __launch_bounds__(256) void splitk_finish_kernel(const float* __restrict__ slab, int splits, long long MN, int N,
@@ -619,14 +726,16 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __res
     }
 }
 
-// column sums of an (rows, C) matrix, stage 1: partial[blk][c]
+// column sums of an (rows, C) matrix, stage 1: partial[blk][c].  16-byte loads, channel group fixed per thread
+// (threads of a block tile [rows-per-iteration][C/VN]), partials combined through LDS.
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ X, float* __restrict__ part, long long rows, int C,
                                                      long long rows_per_block) {
-    __shared__ float sm[256];
+    constexpr int VN = Vec16<T>::N;
+    __shared__ float sm[256][VN + 1];
     const long long r0 = (long long)blockIdx.x * rows_per_block;
     const long long r1 = min(rows, r0 + rows_per_block);
-    if (C >= 256) {
+    if (C % VN != 0 || C / VN > 256) {     // odd widths (2-class logits): scalar path
         for (int c = threadIdx.x; c < C; c += 256) {
             float s = 0.f;
             for (long long r = r0; r < r1; ++r) s += ldf(X + r * C + c);
@@ -634,18 +743,46 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ X, fl
         }
         return;
     }
-    const int rpi = 256 / C;  // rows per iteration
-    const int rr = threadIdx.x / C, c = threadIdx.x % C;
-    float s = 0.f;
+    const int ngrp = C / VN, rpi = 256 / ngrp;
+    const int cg = threadIdx.x % ngrp, rr = threadIdx.x / ngrp;
+    float a[VN];
+#pragma unroll
+    for (int k = 0; k < VN; ++k) a[k] = 0.f;
     if (rr < rpi)
-        for (long long r = r0 + rr; r < r1; r += rpi) s += ldf(X + r * C + c);
-    sm[threadIdx.x] = s;
+        for (long long r = r0 + rr; r < r1; r += rpi) {
+            const Vec16<T> v = ld16(X + r * C + cg * VN);
+#pragma unroll
+            for (int k = 0; k < VN; ++k) a[k] += v.get(k);
+        }
+#pragma unroll
+    for (int k = 0; k < VN; ++k) sm[threadIdx.x][k] = a[k];
     __syncthreads();
-    if (threadIdx.x < C) {
-        float tot = 0.f;
-        for (int k = 0; k < rpi; ++k) tot += sm[k * C + threadIdx.x];
-        part[(long long)blockIdx.x * C + threadIdx.x] = tot;
+    for (int o = threadIdx.x; o < C; o += 256) {
+        const int og = o / VN, ok = o % VN;
+        float s = 0.f;
+        for (int q = 0; q < rpi; ++q) s += sm[q * ngrp + og][ok];
+        part[(long long)blockIdx.x * C + o] = s;
     }
+}
+
+// small-L reduction: one block per output, 256 lanes over the partials (bias gradients: L = Cout <= 512)
+__global__ __launch_bounds__(256) void reduce_partials_small_kernel(const float* __restrict__ part, int P, int L, float* __restrict__ out,
+                                                                    int Cin, int Cout, long long s_t, long long s_c, long long s_n) {
+    __shared__ float red[17];
+    const int i = blockIdx.x;
+    float s = 0.f;
+    for (int p = threadIdx.x; p < P; p += 256) s += part[(long long)p * L + i];
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) {
+        const int co = i % Cout, ci = (i / Cout) % Cin, t = i / (Cout * Cin);
+        out[t * s_t + ci * s_c + co * s_n] = s;
+    }
+}
+
+static void launch_reduce_partials(const float* part, int P, int L, float* out, int Cin, int Cout, long long s_t, long long s_c,
+                                   long long s_n, dycon_stream_t stream) {
+    if (L <= 512 && P > 64) reduce_partials_small_kernel<<<L, 256, 0, stream>>>(part, P, L, out, Cin, Cout, s_t, s_c, s_n);
+    else reduce_partials_kernel<<<cdiv(L, 32), 256, 0, stream>>>(part, P, L, out, Cin, Cout, s_t, s_c, s_n);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -744,6 +881,21 @@ extern "C" int dycon_conv_gemm(const void* x, const void* wfrag, const float* bi
     DYCON_REQUIRE(!scatter || (mode == DYCON_CONV_1X1 && N == 8 * Cout), "conv_gemm: scatter needs mode 1x1 and N == 8*Cout");
     DYCON_REQUIRE(scatter || N == Cout, "conv_gemm: N must equal Cout without scatter");
     DYCON_REQUIRE(mode != DYCON_CONV_K2S2 || (Di % 2 == 0 && Hi % 2 == 0 && Wi % 2 == 0), "conv_gemm: k2s2 needs even dims");
+    // large spatial levels, bf16: LDS-halo kernel
+    if (dtype == DYCON_BF16 && mode == DYCON_CONV_K3 && !scatter && (Cin == 16 || Cin % 32 == 0) &&
+        (Cout == 16 || Cout == 32 || Cout % 64 == 0) && (long long)Di * Hi * Wi >= 13824) {
+        const int tz = cdiv(Di, CL_TZ), ty = cdiv(Hi, CL_TY), tx = cdiv(Wi, CL_TX);
+        const int NT = Cout / 16;
+        const int ntb = Cout >= 64 ? 4 : NT;
+        dim3 grid(B * tz * ty * tx, NT / ntb);
+#define DYCON_CL(CKV, NTBV, WMV) \
+    conv_k3_lds_kernel<CKV, NTBV, WMV><<<grid, 256, 0, stream>>>((const bf16*)x, (const bf16*)wfrag, bias, (bf16*)y, B, Di, Hi, Wi, Cin, Cout, NT, tz, ty, tx, accumulate)
+        if (Cin == 16) { if (ntb == 1) DYCON_CL(16, 1, 4); else if (ntb == 2) DYCON_CL(16, 2, 4); else DYCON_CL(16, 4, 2); }
+        else { if (ntb == 1) DYCON_CL(32, 1, 4); else if (ntb == 2) DYCON_CL(32, 2, 4); else DYCON_CL(32, 4, 2); }
+#undef DYCON_CL
+        DYCON_LAUNCH_CHECK();
+        return DYCON_OK;
+    }
     // split-K only when the caller provides the slab workspace (NULL -> single pass, same result up to fp32 summation order)
     float* ws = (workspace && ws_bytes >= dycon_conv_gemm_workspace(dtype, mode, scatter, B, Di, Hi, Wi, Cin, N)) ? workspace : nullptr;
     DYCON_DISPATCH(dtype, {
@@ -918,10 +1070,10 @@ extern "C" int dycon_conv_wgrad(const void* x, int x_dtype, const void* gy, int 
         else DYCON_WK3(4, false);
 #undef DYCON_WK3
         DYCON_LAUNCH_CHECK();
-        reduce_partials_kernel<<<cdiv(p.L, 32), 256, 0, stream>>>(workspace, k.splits, p.L, dw, Cin, Cout, s_t, s_c, s_n);
+        launch_reduce_partials(workspace, k.splits, p.L, dw, Cin, Cout, s_t, s_c, s_n, stream);
         DYCON_LAUNCH_CHECK();
         if (dbias) {
-            reduce_partials_kernel<<<cdiv(Cout, 32), 256, 0, stream>>>(bpart, k.splits, Cout, dbias, 1, Cout, 0, 0, 1);
+            launch_reduce_partials(bpart, k.splits, Cout, dbias, 1, Cout, 0, 0, 1, stream);
             DYCON_LAUNCH_CHECK();
         }
         return DYCON_OK;
@@ -933,7 +1085,7 @@ extern "C" int dycon_conv_wgrad(const void* x, int x_dtype, const void* gy, int 
         if (x_dtype == DYCON_F32) wgrad_1x1_skinny_kernel<float, float, 16, 2><<<blocks, 256, 0, stream>>>((const float*)x, (const float*)gy, workspace, M);
         else wgrad_1x1_skinny_kernel<bf16, float, 16, 2><<<blocks, 256, 0, stream>>>((const bf16*)x, (const float*)gy, workspace, M);
         DYCON_LAUNCH_CHECK();
-        reduce_partials_kernel<<<cdiv(p.L, 32), 256, 0, stream>>>(workspace, blocks, p.L, dw, Cin, Cout, s_t, s_c, s_n);
+        launch_reduce_partials(workspace, blocks, p.L, dw, Cin, Cout, s_t, s_c, s_n, stream);
         DYCON_LAUNCH_CHECK();
         if (dbias) {
             float* cws = workspace + (size_t)p.splits * p.L;
@@ -947,7 +1099,7 @@ extern "C" int dycon_conv_wgrad(const void* x, int x_dtype, const void* gy, int 
     else if (x_dtype == DYCON_F32 && g_dtype == DYCON_BF16) launch_wgrad<float, bf16>(x, gy, workspace, mode, p, B, Di, Hi, Wi, Cin, Cout, stream);
     else { dycon_set_error("conv_wgrad: bad dtypes"); return DYCON_ERR_INVALID; }
     DYCON_LAUNCH_CHECK();
-    reduce_partials_kernel<<<cdiv(p.L, 32), 256, 0, stream>>>(workspace, p.splits, p.L, dw, Cin, Cout, s_t, s_c, s_n);
+    launch_reduce_partials(workspace, p.splits, p.L, dw, Cin, Cout, s_t, s_c, s_n, stream);
     DYCON_LAUNCH_CHECK();
     if (dbias) {   // un-fused bias gradient: column sums of gy, partials behind the weight partials
         int Do, Ho, Wo;
@@ -960,8 +1112,8 @@ extern "C" int dycon_conv_wgrad(const void* x, int x_dtype, const void* gy, int 
 }
 
 static void colsum_plan(long long rows, int C, int& blocks, long long& rpb) {
-    long long b = (rows + 511) / 512;
-    if (b > 1024) b = 1024;
+    long long b = (rows + 255) / 256;
+    if (b > 2048) b = 2048;
     if (b < 1) b = 1;
     rpb = (rows + b - 1) / b;
     blocks = (int)((rows + rpb - 1) / rpb);
@@ -981,7 +1133,7 @@ extern "C" int dycon_colsum(const void* x, int dtype, float* out, long long rows
     DYCON_REQUIRE(ws_bytes >= (size_t)blocks * C * sizeof(float), "colsum: workspace too small");
     DYCON_DISPATCH(dtype, { colsum_kernel<T><<<blocks, 256, 0, stream>>>((const T*)x, workspace, rows, C, rpb); });
     DYCON_LAUNCH_CHECK();
-    reduce_partials_kernel<<<cdiv(C, 32), 256, 0, stream>>>(workspace, blocks, C, out, 1, C, 0, 0, 1);
+    launch_reduce_partials(workspace, blocks, C, out, 1, C, 0, 0, 1, stream);
     DYCON_LAUNCH_CHECK();
     return DYCON_OK;
 }

@@ -26,7 +26,7 @@ __global__ __launch_bounds__(256) void norm_partial_kernel(const T* __restrict__
                                                            float* __restrict__ part, long long V, int C, int G,
                                                            long long rows_per_chunk, const float* __restrict__ stats,
                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                           int relu, int from_y) {
+                                                           int relu, int from_y, const float* __restrict__ chan_scale) {
     constexpr int VN = Vec16<T>::N;
     __shared__ float sm[2][256][VN + 1];
     const int n = blockIdx.y, chunk = blockIdx.x;
@@ -38,12 +38,13 @@ __global__ __launch_bounds__(256) void norm_partial_kernel(const T* __restrict__
     float a0[VN], a1[VN];
 #pragma unroll
     for (int k = 0; k < VN; ++k) a0[k] = a1[k] = 0.f;
-    float mean[VN], rstd[VN], gm[VN], bt[VN];
+    float mean[VN], rstd[VN], gm[VN], bt[VN], cs[VN];
     if (MODE == 1) {
 #pragma unroll
         for (int k = 0; k < VN; ++k) {
             const int c = cg * VN + k;
             const int g = c / cpg;
+            cs[k] = chan_scale ? chan_scale[(long long)n * C + c] : 1.f;
             mean[k] = stats[((long long)n * G + g) * 2];
             rstd[k] = stats[((long long)n * G + g) * 2 + 1];
             gm[k] = gamma ? gamma[c] : 1.f;
@@ -66,7 +67,7 @@ __global__ __launch_bounds__(256) void norm_partial_kernel(const T* __restrict__
                 const Vec16<T> gv = ld16(gp + v * C);
 #pragma unroll
                 for (int k = 0; k < VN; ++k) {
-                    float xh, g = gv.get(k);
+                    float xh, g = gv.get(k) * cs[k];
                     if (from_y) {
                         const float y = s.get(k);
                         xh = (y - bt[k]) / gm[k];
@@ -162,9 +163,10 @@ __global__ __launch_bounds__(64) void norm_finalize_bwd_kernel(const float* __re
 template <typename T>
 __global__ __launch_bounds__(256) void norm_apply_kernel(const T* __restrict__ X, T* __restrict__ Y, long long V, int C, int G,
                                                          const float* __restrict__ stats, const float* __restrict__ gamma,
-                                                         const float* __restrict__ beta, int relu, const T* __restrict__ skip) {
+                                                         const float* __restrict__ beta, int relu, const T* __restrict__ skip,
+                                                         const float* __restrict__ chan_scale) {
     constexpr int VN = Vec16<T>::N;
-    extern __shared__ float ss[];  // scale[C], shift[C]
+    extern __shared__ float ss[];  // scale[C], shift[C], channel (dropout) scale[C]
     const int n = blockIdx.y, cpg = C / G;
     for (int c = threadIdx.x; c < C; c += 256) {
         const int g = c / cpg;
@@ -172,6 +174,7 @@ __global__ __launch_bounds__(256) void norm_apply_kernel(const T* __restrict__ X
         const float gm = gamma ? gamma[c] : 1.f, bt = beta ? beta[c] : 0.f;
         ss[c] = rstd * gm;
         ss[C + c] = bt - mean * rstd * gm;
+        ss[2 * C + c] = chan_scale ? chan_scale[(long long)n * C + c] : 1.f;
     }
     __syncthreads();
     const long long total = V * C / VN;
@@ -186,6 +189,7 @@ __global__ __launch_bounds__(256) void norm_apply_kernel(const T* __restrict__ X
         for (int k = 0; k < VN; ++k) {
             float v = x.get(k) * ss[c0 + k] + ss[C + c0 + k];
             if (relu) v = v < 0.f ? 0.f : v;   // NaN-propagating, like torch.relu (fmaxf would swallow a NaN)
+            v *= ss[2 * C + c0 + k];           // fused nn.Dropout3d: keep[n,c] / (1-p)   (1 when absent)
             if (skip) v += s.get(k);
             y.set(k, v);
         }
@@ -198,9 +202,10 @@ template <typename T>
 __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(const T* __restrict__ S, const T* __restrict__ GY, T* __restrict__ GX,
                                                              long long V, int C, int G, const float* __restrict__ stats,
                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                             const float* __restrict__ ab, int relu, int from_y) {
+                                                             const float* __restrict__ ab, int relu, int from_y,
+                                                             const float* __restrict__ chan_scale) {
     constexpr int VN = Vec16<T>::N;
-    extern __shared__ float ss[];  // per channel: mean, rstd, gamma, beta, A/cnt, B/cnt
+    extern __shared__ float ss[];  // per channel: mean, rstd, gamma, beta, A/cnt, B/cnt, dropout scale
     const int n = blockIdx.y, cpg = C / G;
     const float inv_cnt = 1.f / ((float)V * (float)cpg);
     for (int c = threadIdx.x; c < C; c += 256) {
@@ -211,6 +216,7 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(const T* __restrict
         ss[3 * C + c] = beta ? beta[c] : 0.f;
         ss[4 * C + c] = ab[((long long)n * G + g) * 2] * inv_cnt;
         ss[5 * C + c] = ab[((long long)n * G + g) * 2 + 1] * inv_cnt;
+        ss[6 * C + c] = chan_scale ? chan_scale[(long long)n * C + c] : 1.f;
     }
     __syncthreads();
     const long long total = V * C / VN;
@@ -224,7 +230,7 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(const T* __restrict
         for (int k = 0; k < VN; ++k) {
             const int c = c0 + k;
             const float gm = ss[2 * C + c], bt = ss[3 * C + c], rstd = ss[C + c];
-            float xh, g = gv.get(k);
+            float xh, g = gv.get(k) * ss[6 * C + c];
             if (from_y) {
                 const float y = s.get(k);
                 xh = (y - bt) / gm;
@@ -263,7 +269,7 @@ extern "C" int dycon_norm_stats(const void* x, int dtype, int Nb, long long V, i
     dim3 grid(p.chunks, Nb);
     DYCON_DISPATCH(dtype, {
         norm_partial_kernel<T, 0><<<grid, 256, 0, stream>>>((const T*)x, nullptr, workspace, V, C, G, p.rows_per_chunk, nullptr,
-                                                            nullptr, nullptr, 0, 0);
+                                                            nullptr, nullptr, 0, 0, nullptr);
     });
     DYCON_LAUNCH_CHECK();
     norm_finalize_stats_kernel<<<Nb * G, 64, 0, stream>>>(workspace, Nb, p.chunks, C, G, V, eps, stats, running_mean, running_var, momentum);
@@ -279,21 +285,23 @@ static int apply_grid(long long V, int C, int VN) {
 }
 
 extern "C" int dycon_norm_apply(const void* x, void* y, int dtype, int Nb, long long V, int C, int G, const float* stats,
-                                const float* gamma, const float* beta, int relu, const void* skip, dycon_stream_t stream) {
+                                const float* gamma, const float* beta, int relu, const void* skip, const float* chan_scale,
+                                dycon_stream_t stream) {
     DYCON_REQUIRE(x && y && stats, "norm_apply: null pointer");
     if (int e = norm_check("norm_apply", dtype, Nb, V, C, G)) return e;
     DYCON_DISPATCH(dtype, {
         dim3 grid(apply_grid(V, C, Vec16<T>::N), Nb);
-        norm_apply_kernel<T><<<grid, 256, 2 * C * sizeof(float), stream>>>((const T*)x, (T*)y, V, C, G, stats, gamma, beta, relu,
-                                                                           (const T*)skip);
+        norm_apply_kernel<T><<<grid, 256, 3 * C * sizeof(float), stream>>>((const T*)x, (T*)y, V, C, G, stats, gamma, beta, relu,
+                                                                           (const T*)skip, chan_scale);
     });
     DYCON_LAUNCH_CHECK();
     return DYCON_OK;
 }
 
 extern "C" int dycon_norm_bwd(const void* src, int from_y, const void* gy, void* gx, int dtype, int Nb, long long V, int C,
-                              int G, const float* stats, const float* gamma, const float* beta, int relu, float* dgamma,
-                              float* dbeta, float* workspace, size_t ws_bytes, dycon_stream_t stream) {
+                              int G, const float* stats, const float* gamma, const float* beta, int relu,
+                              const float* chan_scale, float* dgamma, float* dbeta, float* workspace, size_t ws_bytes,
+                              dycon_stream_t stream) {
     DYCON_REQUIRE(src && gy && gx && stats && workspace, "norm_bwd: null pointer");
     if (int e = norm_check("norm_bwd", dtype, Nb, V, C, G)) return e;
     DYCON_REQUIRE(ws_bytes >= dycon_norm_workspace(Nb, V, C), "norm_bwd: workspace too small");
@@ -302,7 +310,7 @@ extern "C" int dycon_norm_bwd(const void* src, int from_y, const void* gy, void*
     dim3 grid(p.chunks, Nb);
     DYCON_DISPATCH(dtype, {
         norm_partial_kernel<T, 1><<<grid, 256, 0, stream>>>((const T*)src, (const T*)gy, workspace, V, C, G, p.rows_per_chunk,
-                                                            stats, gamma, beta, relu, from_y);
+                                                            stats, gamma, beta, relu, from_y, chan_scale);
     });
     DYCON_LAUNCH_CHECK();
     const int nfin = Nb * G + ((dgamma || dbeta) ? C : 0);
@@ -310,8 +318,8 @@ extern "C" int dycon_norm_bwd(const void* src, int from_y, const void* gy, void*
     DYCON_LAUNCH_CHECK();
     DYCON_DISPATCH(dtype, {
         dim3 grid2(apply_grid(V, C, Vec16<T>::N), Nb);
-        norm_bwd_apply_kernel<T><<<grid2, 256, 6 * C * sizeof(float), stream>>>((const T*)src, (const T*)gy, (T*)gx, V, C, G, stats,
-                                                                                gamma, beta, ab, relu, from_y);
+        norm_bwd_apply_kernel<T><<<grid2, 256, 7 * C * sizeof(float), stream>>>((const T*)src, (const T*)gy, (T*)gx, V, C, G, stats,
+                                                                                gamma, beta, ab, relu, from_y, chan_scale);
     });
     DYCON_LAUNCH_CHECK();
     return DYCON_OK;

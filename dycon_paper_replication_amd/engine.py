@@ -221,7 +221,7 @@ class Engine:
         return y
 
     # ---------------------------------------------------------------- norm (+ReLU, +skip)
-    def _norm(self, prefix, z, kind, relu=True, skip=None, training=True):
+    def _norm(self, prefix, z, kind, relu=True, skip=None, training=True, chan_scale=None):
         B, C = z.shape[0], z.shape[-1]
         V = z.numel() // (B * C)
         gamma = beta = None
@@ -247,7 +247,7 @@ class Engine:
                 self.buf[prefix + ".num_batches_tracked"] += 1
         # z is kept: the ReLU is not invertible, so the backward needs the pre-norm tensor (xhat of the
         # clamped voxels still enters the group means)
-        y = ops.norm_apply(z, stats, Nb, V, C, G, gamma, beta, relu, skip)
+        y = ops.norm_apply(z, stats, Nb, V, C, G, gamma, beta, relu, skip, chan_scale=chan_scale)
         if self.recording:
             def bwd():
                 gy = self._take(y)
@@ -255,29 +255,23 @@ class Engine:
                     self._give(skip, gy)
                 dg = self.g[prefix + ".weight"] if gamma is not None else None
                 db = self.g[prefix + ".bias"] if beta is not None else None
-                gz = ops.norm_bwd(z, False, gy, stats, Nb, V, C, G, gamma, beta, relu, dg, db)
+                gz = ops.norm_bwd(z, False, gy, stats, Nb, V, C, G, gamma, beta, relu, dg, db, chan_scale=chan_scale)
                 self._give(z, gz)
             self.tape.append(bwd)
         return y
 
     # ---------------------------------------------------------------- dropout sites
-    def _drop_channels(self, x, key, p, site):
+    def _channel_scale(self, B, C, key, p, site, device):
+        """nn.Dropout3d(p) as a per-(sample, channel) factor keep/(1-p); applied INSIDE the preceding norm kernel."""
         d = self.dropout
         if d.mode == "off":
-            return x
+            return None
         if d.mode == "mask":
             m = d.masks.get(key)
             if m is None:
-                return x
-            scale = (m.to(torch.float32) / (1.0 - p)).contiguous().reshape(-1)   # tiny (B*C) host-provided mask
-        else:
-            scale = ops.channel_mask_philox(x.shape[0] * x.shape[-1], p, d.seed, d.offset + site * (1 << 20), x.device)
-        y = ops.scale_channels(x, scale)
-        if self.recording:
-            def bwd():
-                self._give(x, ops.scale_channels(self._take(y), scale))
-            self.tape.append(bwd)
-        return y
+                return None
+            return (m.to(torch.float32) / (1.0 - p)).contiguous().reshape(-1)   # tiny (B*C) host-provided mask
+        return ops.channel_mask_philox(B * C, p, d.seed, d.offset + site * (1 << 20), device)
 
     def _drop_elements(self, x, key, p, site):
         d = self.dropout
@@ -317,10 +311,13 @@ class Engine:
     def _vnet(self, x, training):
         nk = "gn" if self.normalization == "groupnorm" else "in"
 
-        def block(name, t, n, first=False):
+        def block(name, t, n, first=False, drop=None):
             for i in range(n):
                 t = self._conv(f"{name}.conv.{3 * i}", t, "k3", need_gx=not (first and i == 0))
-                t = self._norm(f"{name}.conv.{3 * i + 1}", t, nk)
+                cs = None
+                if drop is not None and i == n - 1:
+                    cs = self._channel_scale(t.shape[0], t.shape[-1], drop[0], 0.5, drop[1], t.device)
+                t = self._norm(f"{name}.conv.{3 * i + 1}", t, nk, chan_scale=cs)
             return t
 
         def down(name, t):
@@ -333,13 +330,12 @@ class Engine:
         x2 = block("block_two", down("block_one_dw", x1), 2)
         x3 = block("block_three", down("block_two_dw", x2), 3)
         x4 = block("block_four", down("block_three_dw", x3), 3)
-        x5 = block("block_five", down("block_four_dw", x4), 3)
-        x5 = self._drop_channels(x5, "drop5", 0.5, 0)                       # VNet.py:195-196
+        x5 = block("block_five", down("block_four_dw", x4), 3, drop=("drop5", 0))   # + Dropout3d, VNet.py:195-196
         u = up("block_five_up", x5, x4)
         u = up("block_six_up", block("block_six", u, 3), x3)
         u = up("block_seven_up", block("block_seven", u, 3), x2)
         u = up("block_eight_up", block("block_eight", u, 2), x1)
-        x9 = self._drop_channels(block("block_nine", u, 1), "drop9", 0.5, 1)   # VNet.py:225-226
+        x9 = block("block_nine", u, 1, drop=("drop9", 1))                            # + Dropout3d, VNet.py:225-226
         logits = self._conv("out_conv", x9, "1x1", out_dtype=torch.float32)
         feats = self._head(x5, training)
         return logits, feats, None

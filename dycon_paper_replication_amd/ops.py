@@ -170,21 +170,23 @@ def norm_stats(x, Nb, V, C, G, eps=1e-5, running_mean=None, running_var=None, mo
     return stats
 
 
-def norm_apply(x, stats, Nb, V, C, G, gamma=None, beta=None, relu=True, skip=None, out=None):
+def norm_apply(x, stats, Nb, V, C, G, gamma=None, beta=None, relu=True, skip=None, out=None, chan_scale=None):
     if out is None:
         out = torch.empty_like(x)
     with _Region("norm_apply", x.numel() * _es(x) * (3 if skip is not None else 2), 3 * x.numel()):
-        call("dycon_norm_apply", _p(x), _p(out), dt(x), Nb, V, C, G, _p(stats), _p(gamma), _p(beta), int(relu), _p(skip), _s())
+        call("dycon_norm_apply", _p(x), _p(out), dt(x), Nb, V, C, G, _p(stats), _p(gamma), _p(beta), int(relu), _p(skip),
+             _p(chan_scale), _s())
     return out
 
 
-def norm_bwd(src, from_y, gy, stats, Nb, V, C, G, gamma=None, beta=None, relu=True, dgamma=None, dbeta=None, out=None):
+def norm_bwd(src, from_y, gy, stats, Nb, V, C, G, gamma=None, beta=None, relu=True, dgamma=None, dbeta=None, out=None,
+             chan_scale=None):
     if out is None:
         out = torch.empty_like(gy)
     ws = _ws(query("dycon_norm_workspace", Nb, V, C), gy)
     with _Region("norm_bwd", gy.numel() * _es(gy) * 5, 12 * gy.numel()):
         call("dycon_norm_bwd", _p(src), int(from_y), _p(gy), _p(out), dt(gy), Nb, V, C, G, _p(stats), _p(gamma), _p(beta),
-             int(relu), _p(dgamma), _p(dbeta), _p(ws), ws.numel() * 4, _s())
+             int(relu), _p(chan_scale), _p(dgamma), _p(dbeta), _p(ws), ws.numel() * 4, _s())
     return out
 
 

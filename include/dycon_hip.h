@@ -101,16 +101,17 @@ size_t dycon_norm_workspace(int Nb, long long V, int C);
 int dycon_norm_stats(const void* x, int dtype, int Nb, long long V, int C, int G, float eps,
                      float* stats, float* running_mean, float* running_var, float momentum,
                      float* workspace, size_t ws_bytes, dycon_stream_t stream);
-/* y = act(gamma*(x-mean)*rstd + beta) + skip ; gamma/beta/skip may be NULL; y may alias x */
+/* y = act(gamma*(x-mean)*rstd + beta) * chan_scale[n,c] + skip ; gamma/beta/skip/chan_scale may be
+ * NULL; y may alias x.  chan_scale (Nb, C) = keep/(1-p) fuses nn.Dropout3d (VNet.py:177,196,226). */
 int dycon_norm_apply(const void* x, void* y, int dtype, int Nb, long long V, int C, int G,
                      const float* stats, const float* gamma, const float* beta, int relu,
-                     const void* skip, dycon_stream_t stream);
+                     const void* skip, const float* chan_scale, dycon_stream_t stream);
 /* backward.  src = x (from_y=0, xhat=(x-mean)*rstd) or, ONLY when relu=0 (the op is then
  * invertible), y (from_y=1, xhat=(y-beta)/gamma).  gx may alias gy.  dgamma/dbeta may be NULL. */
 int dycon_norm_bwd(const void* src, int from_y, const void* gy, void* gx, int dtype, int Nb,
                    long long V, int C, int G, const float* stats, const float* gamma,
-                   const float* beta, int relu, float* dgamma, float* dbeta, float* workspace,
-                   size_t ws_bytes, dycon_stream_t stream);
+                   const float* beta, int relu, const float* chan_scale, float* dgamma, float* dbeta,
+                   float* workspace, size_t ws_bytes, dycon_stream_t stream);
 
 /* ---------------------------------------------------------------- data movement / pointwise
  * nn.MaxPool3d(2) (UNet3D_contrastive.py:225-237); idx holds the first-max position 0..7 */

@@ -90,3 +90,28 @@ def test_full_net_bf16_close_to_fp32(kind):
     assert rel < 0.08, rel
     relf = (f16.float() - f32_).abs().max() / f32_.abs().max()
     assert relf < 0.15, relf
+
+
+def test_vnet_dropout3d_masks_vs_oracle():
+    """Dropout3d (fused into the norm kernels) with explicit keep-masks against the oracle, forward and backward."""
+    from dycon_paper_replication_amd.engine import DropoutSpec
+    import torch.nn.functional as F
+    torch.manual_seed(0)
+    eng, p_all = build("vnet", 5)
+    x = torch.randn(2, 1, 32, 32, 32)
+    m5 = (torch.rand(2, 256) > 0.5).float()
+    m9 = (torch.rand(2, 16) > 0.5).float()
+    r1 = torch.randn(2, 2, 32, 32, 32)
+    names = list(ON.trainable(p_all))
+    leaves = {k: p_all[k].clone().requires_grad_(True) for k in names}
+    _, lo_ref, fe_ref = ON.vnet_forward(x, {**p_all, **leaves}, drop5=m5, drop9=m9)
+    grads = torch.autograd.grad((lo_ref * r1).sum() + fe_ref.sum(), [leaves[k] for k in names])
+    spec = DropoutSpec("mask", masks={"drop5": m5.to(DEV), "drop9": m9.to(DEV)})
+    logits, feats, _ = eng.forward(x.permute(0, 2, 3, 4, 1).contiguous().to(DEV), dropout=spec)
+    np.testing.assert_allclose(logits.cpu().permute(0, 4, 1, 2, 3).numpy(), lo_ref.detach().numpy(), rtol=2e-4, atol=2e-4)
+    np.testing.assert_allclose(feats.cpu().permute(0, 4, 1, 2, 3).numpy(), fe_ref.detach().numpy(), rtol=2e-4, atol=2e-4)
+    eng.backward(r1.permute(0, 2, 3, 4, 1).contiguous().to(DEV), torch.ones_like(feats))
+    for k in ("block_nine.conv.0.weight", "block_five.conv.6.weight", "block_one.conv.1.weight", "out_conv.weight"):
+        ref = dict(zip(names, grads))[k]
+        got = eng.g[k].cpu()
+        assert (got - ref).abs().max() <= 2e-3 * ref.abs().max() + 1e-6, k
