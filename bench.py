@@ -23,7 +23,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-MFMA_PEAK_TFLOPS = {"conv_gemm": 2500.0, "conv_wgrad": 157.3}   # dense bf16 MFMA / f32-input MFMA (kernel's arithmetic type)
+MFMA_PEAK_TFLOPS = {"conv_gemm": 2500.0, "conv_k3_lds": 2500.0, "conv_gemm_splitk": 2500.0, "wgrad_k3_bf16": 2500.0, "conv_wgrad": 157.3}   # dense bf16 MFMA / f32-input MFMA (kernel's arithmetic type)
 
 
 def cpu_baseline(model, patch, seed):
@@ -32,7 +32,19 @@ def cpu_baseline(model, patch, seed):
     from oracle import nets as ON
     from oracle import step as OS
     from dycon_paper_replication_amd.synthetic import make_batch
-    cores = os.cpu_count() or 1
+    # the box's CPU share (cgroup / affinity), not the host's logical core count: oversubscribing torch's
+    # intra-op pool makes the CPU path several times slower
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    try:   # cgroup v2 CPU quota, e.g. "1600000 100000" -> 16 CPUs
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            cores = min(cores, max(1, int(q) // int(per)))
+    except (OSError, ValueError):
+        pass
+    cores = max(1, min(cores, 32))
     torch.set_num_threads(cores)
     mk = ON.make_vnet_params if model == "vnet" else ON.make_unet_params
     cfg = OS.StepConfig(net_type=model, labeled_bs=1, feature_scaler=2)

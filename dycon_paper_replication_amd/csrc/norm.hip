@@ -13,8 +13,8 @@
 struct NormPlan { int chunks; long long rows_per_chunk; };
 static NormPlan norm_plan(long long V) {
     NormPlan p;
-    long long rpc = (V + 511) / 512;
-    if (rpc < 512) rpc = 512;
+    long long rpc = (V + 511) / 512;     // <= 512 chunks per sample ...
+    if (rpc < 64) rpc = 64;              // ... of >= 64 rows (small levels: many short chunks, not few long serial ones)
     p.rows_per_chunk = rpc;
     p.chunks = (int)((V + rpc - 1) / rpc);
     return p;

@@ -115,7 +115,10 @@ def conv_gemm(x, wfrag, bias, mode, N, Cout, scatter=False, out=None, accumulate
     rows = out.numel() // Cout if not scatter else x.numel() // Cin
     nws = query("dycon_conv_gemm_workspace", dt(x), mode, int(scatter), B, D, H, W, Cin, N)
     ws = _ws(nws, x) if nws else None
-    with _Region("conv_gemm", (x.numel() + out.numel() * (2 if accumulate else 1)) * _es(x) + taps * Cin * N * _es(x),
+    lds_path = (x.dtype == torch.bfloat16 and mode == CONV_K3 and not scatter and (Cin == 16 or Cin % 32 == 0)
+                and (Cout in (16, 32) or Cout % 64 == 0) and D * H * W >= 13824)
+    rname = "conv_k3_lds" if lds_path else ("conv_gemm_splitk" if nws else "conv_gemm")
+    with _Region(rname, (x.numel() + out.numel() * (2 if accumulate else 1)) * _es(x) + taps * Cin * N * _es(x),
                  2 * rows * taps * Cin * N):
         call("dycon_conv_gemm", _p(x), _p(wfrag), _p(bias), _p(out), dt(x), mode, int(scatter), int(accumulate),
              B, D, H, W, Cin, N, Cout, _p(ws), nws, _s())
@@ -143,7 +146,9 @@ def conv_wgrad(x, gy, dw, mode, s_t, s_c, s_n, dbias=None):
     nbytes = query("dycon_conv_wgrad_workspace", mode, B, D, H, W, Cin, Cout)
     ws = _ws(nbytes, x)
     taps = {CONV_K3: 27, CONV_K2S2: 8, CONV_1X1: 1}[mode]
-    with _Region("conv_wgrad", x.numel() * _es(x) + gy.numel() * _es(gy) + taps * Cin * Cout * 4,
+    k3bf = (x.dtype == torch.bfloat16 and gy.dtype == torch.bfloat16 and mode == CONV_K3 and (Cin % 16 == 0 or Cin == 1)
+            and (Cout in (16, 32) or Cout % 64 == 0))
+    with _Region("wgrad_k3_bf16" if k3bf else "conv_wgrad", x.numel() * _es(x) + gy.numel() * _es(gy) + taps * Cin * Cout * 4,
                  2 * (gy.numel() // Cout) * taps * Cin * Cout):
         call("dycon_conv_wgrad", _p(x), dt(x), _p(gy), dt(gy), _p(dw), _p(dbias), mode, B, D, H, W, Cin, Cout, s_t, s_c, s_n,
              _p(ws), ws.numel() * 4, _s())
