@@ -228,7 +228,8 @@ __global__ __launch_bounds__(256) void conv_k3_lds_kernel(const bf16* __restrict
     constexpr int MTW = 16 / WM;               // m-tiles per wave
     constexpr int NTW = NTB / WN;              // n-tiles per wave
     constexpr int VS = CK == 32 ? 40 : 16;     // LDS voxel stride in elements (80 B / 32 B)
-    __shared__ __attribute__((aligned(16))) unsigned short Xh[CL_NH * VS];
+    constexpr int LDS_ELEMS = CL_NH * VS > CL_NV * (NTB * 16 + 8) ? CL_NH * VS : CL_NV * (NTB * 16 + 8);
+    __shared__ __attribute__((aligned(16))) unsigned short Xh[LDS_ELEMS];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 15, kg = lane >> 4;
     const int wm = wave / WN, wn = wave % WN;
@@ -259,17 +260,25 @@ __global__ __launch_bounds__(256) void conv_k3_lds_kernel(const bf16* __restrict
         __syncthreads();
         // ---- stage the halo tile of channels [ch*CK, ch*CK + CK)
         constexpr int PPV = CK / 8;                            // 16-byte pieces per voxel
-        for (int e = threadIdx.x; e < CL_NH * PPV; e += 256) {
+        constexpr int NST = (CL_NH * PPV + 255) / 256;         // staging pieces per thread
+        uint4 stg[NST];
+#pragma unroll
+        for (int it = 0; it < NST; ++it) {                     // all loads in flight first ...
+            const int e = threadIdx.x + 256 * it;
             const int hv = e / PPV, pc = e % PPV;
             const int hx = hv % CL_HX, hy = (hv / CL_HX) % CL_HY, hz = hv / (CL_HX * CL_HY);
             const int z = z0 + hz - 1, y = y0 + hy - 1, x = x0 + hx - 1;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if ((unsigned)z < (unsigned)D && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W)
-                v = *reinterpret_cast<const uint4*>(X + ((((long long)b * D + z) * H + y) * W + x) * Cin + ch * CK + 8 * pc);
-            *reinterpret_cast<uint4*>(Xh + hv * VS + 8 * pc) = v;
+            stg[it] = make_uint4(0, 0, 0, 0);
+            if (e < CL_NH * PPV && (unsigned)z < (unsigned)D && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W)
+                stg[it] = *reinterpret_cast<const uint4*>(X + ((((long long)b * D + z) * H + y) * W + x) * Cin + ch * CK + 8 * pc);
+        }
+#pragma unroll
+        for (int it = 0; it < NST; ++it) {                     // ... then the LDS writes
+            const int e = threadIdx.x + 256 * it;
+            if (e < CL_NH * PPV) *reinterpret_cast<uint4*>(Xh + (e / PPV) * VS + 8 * (e % PPV)) = stg[it];
         }
         __syncthreads();
-#pragma unroll 3
+#pragma unroll 2
         for (int ks = 0; ks < NKS; ++ks) {
             int t, coff;
             if (CK == 32) { t = ks; coff = 8 * kg; }
@@ -289,23 +298,38 @@ __global__ __launch_bounds__(256) void conv_k3_lds_kernel(const bf16* __restrict
             }
         }
     }
-    // ---- epilogue: D tile row = 4*kg + i (voxel), col = r (channel)
+    // ---- epilogue through LDS: the D fragments hold one channel per lane (2-byte scattered stores would be
+    //      store-issue bound); stage the 256 x CBW bf16 tile in LDS and write whole 16-byte channel groups
+    constexpr int CBW = NTB * 16;                  // channels of this workgroup
+    constexpr int OS = CBW + 8;                    // LDS row stride (elements): +16 B against bank conflicts
+    __syncthreads();                               // all waves are done reading the halo
+    unsigned short* Ot = Xh;
 #pragma unroll
-    for (int m = 0; m < MTW; ++m) {
+    for (int m = 0; m < MTW; ++m)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int v = (wm * MTW + m) * 16 + 4 * kg + i;
-            const int z = z0 + (v >> 6), y = y0 + ((v >> 3) & 7), x = x0 + (v & 7);
-            if (z >= D || y >= H || x >= W) continue;
-            bf16* yp = Y + ((((long long)b * D + z) * H + y) * W + x) * Cout;
+        for (int j = 0; j < NTW; ++j) {
+            const int nl = (wn * NTW + j) * 16 + r;
+            const float bv = bias ? bias[blockIdx.y * CBW + nl] : 0.f;
 #pragma unroll
-            for (int j = 0; j < NTW; ++j) {
-                const int n = (nt0 + j) * 16 + r;
-                float val = acc[m][j][i] + (bias ? bias[n] : 0.f);
-                if (accumulate) val += __bfloat162float(yp[n]);
-                yp[n] = __float2bfloat16(val);
-            }
+            for (int i = 0; i < 4; ++i) Ot[((wm * MTW + m) * 16 + 4 * kg + i) * OS + nl] = f32_to_bf16_bits(acc[m][j][i] + bv);
         }
+    __syncthreads();
+    constexpr int PPR = CBW / 8;                   // 16-byte pieces per voxel row
+#pragma unroll
+    for (int it = 0; it < CL_NV * PPR / 256; ++it) {
+        const int e = threadIdx.x + 256 * it;
+        const int v = e / PPR, pc = e % PPR;
+        const int z = z0 + (v >> 6), y = y0 + ((v >> 3) & 7), x = x0 + (v & 7);
+        if (z >= D || y >= H || x >= W) continue;
+        bf16* yp = Y + ((((long long)b * D + z) * H + y) * W + x) * Cout + blockIdx.y * CBW + 8 * pc;
+        Vec16<bf16> o;
+        o.v = *reinterpret_cast<const uint4*>(Ot + v * OS + 8 * pc);
+        if (accumulate) {
+            const Vec16<bf16> old = ld16(yp);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) o.set(k, o.get(k) + old.get(k));
+        }
+        st16(yp, o);
     }
 }
 
@@ -503,25 +527,44 @@ __global__ __launch_bounds__(256, 2) void wgrad_k3_bf16_kernel(const bf16* __res
                 *reinterpret_cast<uint4*>(Xh + hv * 16) = make_uint4(v0, 0, 0, 0);
                 *reinterpret_cast<uint4*>(Xh + hv * 16 + 8) = make_uint4(0, 0, 0, 0);
             }
-        } else
-        for (int e = threadIdx.x; e < WG_NH * 2; e += 256) {
-            const int hv = e >> 1, half = e & 1;
-            const int hx = hv % WG_HX, hy = (hv / WG_HX) % WG_HY, hz = hv / (WG_HX * WG_HY);
-            const int z = z0 + hz - 1, y = y0 + hy - 1, x = x0 + hx - 1;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if ((unsigned)z < (unsigned)D && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W)
-                v = *reinterpret_cast<const uint4*>(X + ((((long long)b * D + z) * H + y) * W + x) * Cin + ci0 + 8 * half);
-            *reinterpret_cast<uint4*>(Xh + hv * 16 + 8 * half) = v;
+        } else {
+            constexpr int NSX = (WG_NH * 2 + 255) / 256;
+            uint4 sx[NSX];
+#pragma unroll
+            for (int it = 0; it < NSX; ++it) {
+                const int e = threadIdx.x + 256 * it;
+                const int hv = e >> 1, half = e & 1;
+                const int hx = hv % WG_HX, hy = (hv / WG_HX) % WG_HY, hz = hv / (WG_HX * WG_HY);
+                const int z = z0 + hz - 1, y = y0 + hy - 1, x = x0 + hx - 1;
+                sx[it] = make_uint4(0, 0, 0, 0);
+                if (e < WG_NH * 2 && (unsigned)z < (unsigned)D && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W)
+                    sx[it] = *reinterpret_cast<const uint4*>(X + ((((long long)b * D + z) * H + y) * W + x) * Cin + ci0 + 8 * half);
+            }
+#pragma unroll
+            for (int it = 0; it < NSX; ++it) {
+                const int e = threadIdx.x + 256 * it;
+                if (e < WG_NH * 2) *reinterpret_cast<uint4*>(Xh + (e >> 1) * 16 + 8 * (e & 1)) = sx[it];
+            }
         }
-        // ---- stage G tile: 128 voxels x CB channels
-        for (int e = threadIdx.x; e < WG_NV * (CB / 8); e += 256) {
-            const int v8 = e % (CB / 8), vv = e / (CB / 8);
-            const int vx = vv % WG_TX, vy = (vv / WG_TX) % WG_TY, vz = vv / (WG_TX * WG_TY);
-            const int z = z0 + vz, y = y0 + vy, x = x0 + vx;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (z < D && y < H && x < W && co0 + 8 * v8 < Cout)
-                v = *reinterpret_cast<const uint4*>(GY + ((((long long)b * D + z) * H + y) * W + x) * Cout + co0 + 8 * v8);
-            *reinterpret_cast<uint4*>(Gt + vv * CB + 8 * v8) = v;
+        // ---- stage G tile: 128 voxels x CB channels (all loads first, then the LDS writes)
+        {
+            constexpr int NSG = WG_NV * (CB / 8) / 256 > 0 ? WG_NV * (CB / 8) / 256 : 1;
+            uint4 sg[NSG];
+#pragma unroll
+            for (int it = 0; it < NSG; ++it) {
+                const int e = threadIdx.x + 256 * it;
+                const int v8 = e % (CB / 8), vv = e / (CB / 8);
+                const int vx = vv % WG_TX, vy = (vv / WG_TX) % WG_TY, vz = vv / (WG_TX * WG_TY);
+                const int z = z0 + vz, y = y0 + vy, x = x0 + vx;
+                sg[it] = make_uint4(0, 0, 0, 0);
+                if (e < WG_NV * (CB / 8) && z < D && y < H && x < W && co0 + 8 * v8 < Cout)
+                    sg[it] = *reinterpret_cast<const uint4*>(GY + ((((long long)b * D + z) * H + y) * W + x) * Cout + co0 + 8 * v8);
+            }
+#pragma unroll
+            for (int it = 0; it < NSG; ++it) {
+                const int e = threadIdx.x + 256 * it;
+                if (e < WG_NV * (CB / 8)) *reinterpret_cast<uint4*>(Gt + (e / (CB / 8)) * CB + 8 * (e % (CB / 8))) = sg[it];
+            }
         }
         __syncthreads();
         // ---- 4 k-steps of 32 voxels: lane group kg owns x-row (z, y) = ((4s+kg)>>2, (4s+kg)&3), voxels x = 0..7
@@ -735,7 +778,20 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ X, fl
     __shared__ float sm[256][VN + 1];
     const long long r0 = (long long)blockIdx.x * rows_per_block;
     const long long r1 = min(rows, r0 + rows_per_block);
-    if (C % VN != 0 || C / VN > 256) {     // odd widths (2-class logits): scalar path
+    if (C <= 8 && 256 % C == 0) {          // skinny widths (2-class logits): threads tile [rows][C], LDS tree over rows
+        const int c = threadIdx.x % C, rr = threadIdx.x / C, rpi2 = 256 / C;
+        float s = 0.f;
+        for (long long r = r0 + rr; r < r1; r += rpi2) s += ldf(X + r * C + c);
+        sm[threadIdx.x][0] = s;
+        __syncthreads();
+        if (threadIdx.x < C) {
+            float tot = 0.f;
+            for (int q = 0; q < rpi2; ++q) tot += sm[q * C + threadIdx.x][0];
+            part[(long long)blockIdx.x * C + threadIdx.x] = tot;
+        }
+        return;
+    }
+    if (C % VN != 0 || C / VN > 256) {     // other odd widths: scalar path
         for (int c = threadIdx.x; c < C; c += 256) {
             float s = 0.f;
             for (long long r = r0; r < r1; ++r) s += ldf(X + r * C + c);

@@ -352,16 +352,23 @@ __device__ __forceinline__ float row16_max(float v) {
     return v;
 }
 
+// fp32 storage (parity mode): IEEE expf/logf/division.  bf16 storage: hardware v_exp/v_log/v_rcp forms (1e-6 relative,
+// far below the bf16 rounding of the operands) -- the pair epilogue is the VALU-bound part of FeCL.
+template <bool FAST> __device__ __forceinline__ float fexp(float x) { return FAST ? __expf(x) : expf(x); }
+template <bool FAST> __device__ __forceinline__ float flog(float x) { return FAST ? __logf(x) : logf(x); }
+template <bool FAST> __device__ __forceinline__ float fdiv(float a, float b) { return FAST ? __fdividef(a, b) : a / b; }
+
 // d/dP of phi(P) = -log(P+eps) * (1-P)^gamma   (gamma = 0 <=> no focal weight)
+template <bool FAST>
 __device__ __forceinline__ void focal_terms(float P, float gamma, int focal, float& phi, float& dphi) {
     const float eps = 1e-18f;
-    const float lg = logf(P + eps);
-    if (!focal) { phi = -lg; dphi = -1.f / (P + eps); return; }
+    const float lg = flog<FAST>(P + eps);
+    if (!focal) { phi = -lg; dphi = -fdiv<FAST>(1.f, P + eps); return; }
     const float om = fmaxf(1.f - P, 0.f);
     const float w = gamma == 2.f ? om * om : powf(om, gamma);
     const float dw = gamma == 2.f ? 2.f * om : (om > 0.f ? gamma * powf(om, gamma - 1.f) : 0.f);
     phi = -lg * w;
-    dphi = -w / (P + eps) + dw * lg;
+    dphi = -fdiv<FAST>(w, P + eps) + dw * lg;
 }
 
 // PASS: 1 row max | 2 negative sums + class counts | 3 loss + H (+ cross sums) | 4 gradient
@@ -373,6 +380,7 @@ __global__ __launch_bounds__(256) void fecl_kernel(const T* __restrict__ F, cons
                                                    T* __restrict__ GF, int Btot) {
     typedef typename FeclTile<T>::E E;
     constexpr int KS = FeclTile<T>::KS;
+    constexpr bool FAST = sizeof(T) == 2;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     E* lds = reinterpret_cast<E*>(lds_raw);
     const int Dp = (Dm + KS - 1) / KS * KS, stride = Dp + FeclTile<T>::PAD, nq = Dp / KS;
@@ -440,7 +448,7 @@ __global__ __launch_bounds__(256) void fecl_kernel(const T* __restrict__ F, cons
                 const int gj = j0 + 16 * j + r;
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
-                    if (gj < N && gj != gi[i]) a0[i] = fmaxf(a0[i], acc[j][i] / tau);
+                    if (gj < N && gj != gi[i]) a0[i] = fmaxf(a0[i], fdiv<FAST>(acc[j][i], tau));
             }
         } else if (PASS == 2) {
 #pragma unroll
@@ -451,7 +459,7 @@ __global__ __launch_bounds__(256) void fecl_kernel(const T* __restrict__ F, cons
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     if (mk == mrow[i]) a1[i] += 1.f;
-                    else a0[i] += expf(acc[j][i] / tau - mj);
+                    else a0[i] += fexp<FAST>(fdiv<FAST>(acc[j][i], tau) - mj);
                 }
             }
         } else if (PASS == 3) {
@@ -465,13 +473,13 @@ __global__ __launch_bounds__(256) void fecl_kernel(const T* __restrict__ F, cons
                     if (mk == mrow[i]) {
                         a1[i] += 1.f;
                         if (gj != gi[i]) {
-                            const float a = expf(acc[j][i] / tau - mj);
+                            const float a = fexp<FAST>(fdiv<FAST>(acc[j][i], tau) - mj);
                             const float den = a + nrow[i] + 1e-18f;
-                            const float P = a / den;
+                            const float P = fdiv<FAST>(a, den);
                             float phi, dphi;
-                            focal_terms(P, gamma, focal, phi, dphi);
+                            focal_terms<FAST>(P, gamma, focal, phi, dphi);
                             a0[i] += phi;
-                            hrow[i] += dphi * (-a / (den * den));
+                            hrow[i] += dphi * (-fdiv<FAST>(a, den * den));
                         }
                     }
                 }
@@ -487,20 +495,20 @@ __global__ __launch_bounds__(256) void fecl_kernel(const T* __restrict__ F, cons
                 for (int i = 0; i < 4; ++i) {
                     float tv = 0.f;
                     if (vj && vi[i] && gj != gi[i]) {
-                        const float l = acc[j][i] / tau;
-                        const float aij = expf(l - mj), aji = expf(l - mi[i]);
+                        const float l = fdiv<FAST>(acc[j][i], tau);
+                        const float aij = fexp<FAST>(l - mj), aji = fexp<FAST>(l - mi[i]);
                         if (mk == mrow[i]) {
                             float phi, dphi;
                             const float dij = aij + nrow[i] + 1e-18f;
-                            focal_terms(aij / dij, gamma, focal, phi, dphi);
-                            tv = aij * krow[i] * dphi * (nrow[i] + 1e-18f) / (dij * dij);
+                            focal_terms<FAST>(fdiv<FAST>(aij, dij), gamma, focal, phi, dphi);
+                            tv = fdiv<FAST>(aij * krow[i] * dphi * (nrow[i] + 1e-18f), dij * dij);
                             const float dji = aji + nj + 1e-18f;
-                            focal_terms(aji / dji, gamma, focal, phi, dphi);
-                            tv += aji * kj * dphi * (nj + 1e-18f) / (dji * dji);
+                            focal_terms<FAST>(fdiv<FAST>(aji, dji), gamma, focal, phi, dphi);
+                            tv += fdiv<FAST>(aji * kj * dphi * (nj + 1e-18f), dji * dji);
                         } else {
                             tv = aij * hrow[i] + aji * hj;
                         }
-                        tv *= stud_scale / tau;
+                        tv *= stud_scale / tau;   // (uniform scalar)
                     }
                     put_weight(Tt, (16 * wave + 4 * kg + i) * tstride + 16 * j + r, tv);
                 }
@@ -524,9 +532,9 @@ __global__ __launch_bounds__(256) void fecl_kernel(const T* __restrict__ F, cons
                     const float sx = acc[j][i];
                     const bool hard = vj && vi[i] && mk != mrow[i] && sx > thr;
                     if (PASS == 3) {
-                        if (hard) { cnum += -logf(1.f - sx + 1e-18f); ccnt += 1.f; }
+                        if (hard) { cnum += -flog<FAST>(1.f - sx + 1e-18f); ccnt += 1.f; }
                     } else {
-                        put_weight(Tt, (16 * wave + 4 * kg + i) * tstride + 16 * j + r, hard ? cross_scale / (1.f - sx + 1e-18f) : 0.f);
+                        put_weight(Tt, (16 * wave + 4 * kg + i) * tstride + 16 * j + r, hard ? fdiv<FAST>(cross_scale, 1.f - sx + 1e-18f) : 0.f);
                     }
                 }
             }
