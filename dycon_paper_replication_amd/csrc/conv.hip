@@ -163,42 +163,47 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const T* __restrict__ X,
         }
         return;
     }
+    // Stage the 64 x (NTB*16) tile through LDS (one channel per lane in the D fragments) and write 16-byte channel
+    // groups: a lane-per-element epilogue is store-issue bound (2-byte stores) on the big levels.
+    constexpr int VN = Vec16<T>::N;
+    constexpr int OS = NTB * 16 + VN;                       // padded LDS row stride (elements)
+    __shared__ __attribute__((aligned(16))) T Ot[64 * OS];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const long long mo = (long long)blockIdx.x * 64 + wave * 16 + kg * 4 + i;
-        if (mo >= M) continue;
-        long long rowbase;
-        int ox = 0, oy = 0, oz = 0, ob = 0;
+    for (int j = 0; j < NTB; ++j) {
+        const int n = (nt0 + j) * 16 + r;
+        float bv = 0.f;
+        if (bias && nt0 + j < NT && n < N) bv = bias[SCATTER ? n % Cout : n];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) stf(Ot + (wave * 16 + kg * 4 + i) * OS + j * 16 + r, acc[j][i] + bv);
+    }
+    __syncthreads();
+    constexpr int PPR = NTB * 16 / VN;                      // 16-byte pieces per row
+    for (int e = threadIdx.x; e < 64 * PPR; e += 256) {
+        const int row = e / PPR, pc = e % PPR;
+        const long long mo = (long long)blockIdx.x * 64 + row;
+        const int n0 = nt0 * 16 + pc * VN;
+        if (mo >= M || n0 >= N) continue;
+        long long off;
         if (SCATTER) {
             long long q = mo;
-            ox = (int)(q % Wo); q /= Wo;
-            oy = (int)(q % Ho); q /= Ho;
-            oz = (int)(q % Do);
-            ob = (int)(q / Do);
-            rowbase = 0;
+            const int ox = (int)(q % Wo); q /= Wo;
+            const int oy = (int)(q % Ho); q /= Ho;
+            const int oz = (int)(q % Do);
+            const int ob = (int)(q / Do);
+            const int tap = n0 / Cout, co = n0 - tap * Cout;   // Cout % VN == 0: a piece never straddles two taps
+            const long long ov = (((long long)ob * (2 * Do) + 2 * oz + (tap >> 2)) * (2 * Ho) + 2 * oy + ((tap >> 1) & 1)) * (2 * Wo) +
+                                 2 * ox + (tap & 1);
+            off = ov * Cout + co;
         } else {
-            rowbase = mo * N;
+            off = mo * N + n0;
         }
+        Vec16<T> o = ld16(Ot + row * OS + pc * VN);
+        if (accumulate) {
+            const Vec16<T> old = ld16(Y + off);
 #pragma unroll
-        for (int j = 0; j < NTB; ++j) {
-            if (nt0 + j >= NT) continue;
-            const int n = (nt0 + j) * 16 + r;
-            if (n >= N) continue;
-            float v = acc[j][i];
-            long long off;
-            if (SCATTER) {
-                const int tap = n / Cout, co = n - tap * Cout;
-                if (bias) v += bias[co];
-                const long long ov = (((long long)ob * (2 * Do) + 2 * oz + (tap >> 2)) * (2 * Ho) + 2 * oy + ((tap >> 1) & 1)) * (2 * Wo) +
-                                     2 * ox + (tap & 1);
-                off = ov * Cout + co;
-            } else {
-                if (bias) v += bias[n];
-                off = rowbase + n;
-            }
-            if (accumulate) v += ldf(Y + off);
-            stf(Y + off, v);
+            for (int k = 0; k < VN; ++k) o.set(k, o.get(k) + old.get(k));
         }
+        st16(Y + off, o);
     }
 }
 
@@ -219,7 +224,7 @@ constexpr int CL_HZ = CL_TZ + 2, CL_HY = CL_TY + 2, CL_HX = CL_TX + 2;
 constexpr int CL_NH = CL_HZ * CL_HY * CL_HX;     // 600 halo voxels
 constexpr int CL_NV = CL_TZ * CL_TY * CL_TX;     // 256 voxels = 16 m-tiles
 
-template <int CK, int NTB, int WM>
+template <int CK, int NTB, int WM, bool CIN1 = false>
 __global__ __launch_bounds__(256) void conv_k3_lds_kernel(const bf16* __restrict__ X, const bf16* __restrict__ Wf,
                                                           const float* __restrict__ bias, bf16* __restrict__ Y, int B, int D, int H,
                                                           int W, int Cin, int Cout, int NT, int tilesZ, int tilesY, int tilesX,
@@ -254,7 +259,7 @@ __global__ __launch_bounds__(256) void conv_k3_lds_kernel(const bf16* __restrict
         const int v = (wm * MTW + m) * 16 + r;                 // voxel index inside the tile: (z, y, x) = (v/64, (v/8)%8, v%8)
         vbase[m] = (((v >> 6) * CL_HY + ((v >> 3) & 7)) * CL_HX + (v & 7)) * VS;
     }
-    const int nChunks = Cin / CK;
+    const int nChunks = CIN1 ? 1 : Cin / CK;
     constexpr int NKS = CK == 32 ? 27 : 14;                    // MFMA k-steps (32 wide) per chunk
     for (int ch = 0; ch < nChunks; ++ch) {
         __syncthreads();
@@ -262,6 +267,21 @@ __global__ __launch_bounds__(256) void conv_k3_lds_kernel(const bf16* __restrict
         constexpr int PPV = CK / 8;                            // 16-byte pieces per voxel
         constexpr int NST = (CL_NH * PPV + 255) / 256;         // staging pieces per thread
         uint4 stg[NST];
+        if (CIN1) {
+            // first layer (one input channel): channel 0 of the 16-wide LDS rows carries x, channels 1..15 are ZERO, so
+            // the packed weights may alias channel 0 for every c (pack with s_c = 0): 0 * w contributes nothing
+#pragma unroll
+            for (int it = 0; it < NST; ++it) {
+                const int e = threadIdx.x + 256 * it;
+                const int hv = e / PPV, pc = e % PPV;
+                const int hx = hv % CL_HX, hy = (hv / CL_HX) % CL_HY, hz = hv / (CL_HX * CL_HY);
+                const int z = z0 + hz - 1, y = y0 + hy - 1, x = x0 + hx - 1;
+                unsigned v0 = 0;
+                if (pc == 0 && e < CL_NH * PPV && (unsigned)z < (unsigned)D && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W)
+                    v0 = reinterpret_cast<const unsigned short*>(X)[(((long long)b * D + z) * H + y) * W + x];
+                stg[it] = make_uint4(v0, 0, 0, 0);
+            }
+        } else
 #pragma unroll
         for (int it = 0; it < NST; ++it) {                     // all loads in flight first ...
             const int e = threadIdx.x + 256 * it;
@@ -932,13 +952,14 @@ extern "C" int dycon_conv_gemm(const void* x, const void* wfrag, const float* bi
     DYCON_REQUIRE(x && wfrag && y, "conv_gemm: null pointer");
     DYCON_REQUIRE(B > 0 && Di > 0 && Hi > 0 && Wi > 0 && Cin > 0 && N > 0 && Cout > 0, "conv_gemm: bad shape");
     DYCON_REQUIRE(mode >= 0 && mode <= 2, "conv_gemm: bad mode %d", mode);
-    DYCON_REQUIRE(Cin % (dtype == DYCON_BF16 ? 8 : 4) == 0, "conv_gemm: Cin=%d not a multiple of the fragment width", Cin);
+    const bool first_layer_lds = dtype == DYCON_BF16 && mode == DYCON_CONV_K3 && !scatter && Cin == 1 && (long long)Di * Hi * Wi >= 13824;
+    DYCON_REQUIRE(first_layer_lds || Cin % (dtype == DYCON_BF16 ? 8 : 4) == 0, "conv_gemm: Cin=%d not a multiple of the fragment width", Cin);
     DYCON_REQUIRE(N % 16 == 0, "conv_gemm: N=%d not a multiple of 16 (use dycon_conv_direct)", N);
     DYCON_REQUIRE(!scatter || (mode == DYCON_CONV_1X1 && N == 8 * Cout), "conv_gemm: scatter needs mode 1x1 and N == 8*Cout");
     DYCON_REQUIRE(scatter || N == Cout, "conv_gemm: N must equal Cout without scatter");
     DYCON_REQUIRE(mode != DYCON_CONV_K2S2 || (Di % 2 == 0 && Hi % 2 == 0 && Wi % 2 == 0), "conv_gemm: k2s2 needs even dims");
     // large spatial levels, bf16: LDS-halo kernel
-    if (dtype == DYCON_BF16 && mode == DYCON_CONV_K3 && !scatter && (Cin == 16 || Cin % 32 == 0) &&
+    if (dtype == DYCON_BF16 && mode == DYCON_CONV_K3 && !scatter && (Cin == 1 || Cin == 16 || Cin % 32 == 0) &&
         (Cout == 16 || Cout == 32 || Cout % 64 == 0) && (long long)Di * Hi * Wi >= 13824) {
         const int tz = cdiv(Di, CL_TZ), ty = cdiv(Hi, CL_TY), tx = cdiv(Wi, CL_TX);
         const int NT = Cout / 16;
@@ -946,7 +967,11 @@ extern "C" int dycon_conv_gemm(const void* x, const void* wfrag, const float* bi
         dim3 grid(B * tz * ty * tx, NT / ntb);
 #define DYCON_CL(CKV, NTBV, WMV) \
     conv_k3_lds_kernel<CKV, NTBV, WMV><<<grid, 256, 0, stream>>>((const bf16*)x, (const bf16*)wfrag, bias, (bf16*)y, B, Di, Hi, Wi, Cin, Cout, NT, tz, ty, tx, accumulate)
-        if (Cin == 16) { if (ntb == 1) DYCON_CL(16, 1, 4); else if (ntb == 2) DYCON_CL(16, 2, 4); else DYCON_CL(16, 4, 2); }
+        if (Cin == 1) {   // wfrag packed as Cin = 16 with channel stride 0 (see the kernel)
+            if (ntb == 1) conv_k3_lds_kernel<16, 1, 4, true><<<grid, 256, 0, stream>>>((const bf16*)x, (const bf16*)wfrag, bias, (bf16*)y, B, Di, Hi, Wi, 1, Cout, NT, tz, ty, tx, accumulate);
+            else if (ntb == 2) conv_k3_lds_kernel<16, 2, 4, true><<<grid, 256, 0, stream>>>((const bf16*)x, (const bf16*)wfrag, bias, (bf16*)y, B, Di, Hi, Wi, 1, Cout, NT, tz, ty, tx, accumulate);
+            else conv_k3_lds_kernel<16, 4, 2, true><<<grid, 256, 0, stream>>>((const bf16*)x, (const bf16*)wfrag, bias, (bf16*)y, B, Di, Hi, Wi, 1, Cout, NT, tz, ty, tx, accumulate);
+        } else if (Cin == 16) { if (ntb == 1) DYCON_CL(16, 1, 4); else if (ntb == 2) DYCON_CL(16, 2, 4); else DYCON_CL(16, 4, 2); }
         else { if (ntb == 1) DYCON_CL(32, 1, 4); else if (ntb == 2) DYCON_CL(32, 2, 4); else DYCON_CL(32, 4, 2); }
 #undef DYCON_CL
         DYCON_LAUNCH_CHECK();

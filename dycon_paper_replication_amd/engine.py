@@ -178,7 +178,12 @@ class Engine:
         gq = 8 if dtype == torch.bfloat16 else 4
         skinny = (Cin % gq != 0) or (Cout % 16 != 0)
         out_dtype = out_dtype or dtype
-        if skinny:
+        first_lds = (kind == "k3" and Cin == 1 and dtype == torch.bfloat16 and Cout % 16 == 0 and out_dtype == dtype
+                     and x.shape[1] * x.shape[2] * x.shape[3] >= 13824)
+        if first_lds:   # first layer on the matrix cores: weights packed as 16 aliased channels (stride 0), see dycon_hip.h
+            wf = self._pk((name, "f1"), lambda o: ops.pack_bfrag(w, dtype, 27, 16, Cout, Cout, 1, 0, 0, 27, out=o))
+            y = ops.conv_gemm(x, wf, b, CONV_K3, Cout, Cout)
+        elif skinny:
             assert kind in ("k3", "1x1"), "skinny path only for the first conv and the 1x1 heads"
             wt = self._pk((name, "tcn"), lambda o: ops.pack_tcn(w, T, Cin, Cout, Cout, 1, T, 0, Cin * T, out=o))
             y = ops.conv_direct(x, wt, b, mode, Cout, out_dtype)

@@ -115,7 +115,7 @@ def conv_gemm(x, wfrag, bias, mode, N, Cout, scatter=False, out=None, accumulate
     rows = out.numel() // Cout if not scatter else x.numel() // Cin
     nws = query("dycon_conv_gemm_workspace", dt(x), mode, int(scatter), B, D, H, W, Cin, N)
     ws = _ws(nws, x) if nws else None
-    lds_path = (x.dtype == torch.bfloat16 and mode == CONV_K3 and not scatter and (Cin == 16 or Cin % 32 == 0)
+    lds_path = (x.dtype == torch.bfloat16 and mode == CONV_K3 and not scatter and (Cin in (1, 16) or Cin % 32 == 0)
                 and (Cout in (16, 32) or Cout % 64 == 0) and D * H * W >= 13824)
     rname = "conv_k3_lds" if lds_path else ("conv_gemm_splitk" if nws else "conv_gemm")
     with _Region(rname, (x.numel() + out.numel() * (2 if accumulate else 1)) * _es(x) + taps * Cin * N * _es(x),

@@ -62,6 +62,10 @@ CONV_CASES = [
     ("k2s2", 16, 32, (8, 6, 10)), ("k2s2", 64, 128, (4, 4, 2)),
     ("deconv", 32, 16, (4, 3, 5)), ("deconv", 128, 64, (2, 3, 2)),
     ("1x1", 256, 512, (2, 3, 2)), ("1x1", 16, 2, (4, 6, 8)), ("k3", 1, 16, (8, 8, 12)),
+    # >= 24^3 voxels: the LDS-halo kernels (all CK / NTB / wave-layout variants, partial tiles, first layer)
+    ("k3", 1, 16, (24, 24, 24)), ("k3", 16, 16, (24, 28, 22)), ("k3", 16, 32, (24, 24, 24)), ("k3", 32, 16, (24, 24, 24)),
+    ("k3", 32, 32, (26, 24, 24)), ("k3", 64, 64, (24, 24, 24)), ("k3", 16, 64, (24, 24, 24)), ("k3", 64, 128, (24, 24, 24)),
+    ("k3", 32, 1 * 16, (20, 28, 25)),
 ]
 
 
@@ -104,8 +108,9 @@ def test_conv(kind, cin, cout, sp, dtype):
     torch.cuda.synchronize()
     if dtype == torch.float32:
         close(nc(y), yr, 1e-4, 1e-5, "y")
-        close(e.g["l.weight"], wr.grad, 1e-4, 2e-4, "gw")
-        close(e.g["l.bias"], br.grad, 1e-4, 2e-4, "gb")
+        # sums over up to 3e4 voxels: elements that nearly cancel carry the round-off of the large terms
+        close(e.g["l.weight"], wr.grad, 1e-4, 2e-4 + 1e-5 * float(wr.grad.abs().max()), "gw")
+        close(e.g["l.bias"], br.grad, 1e-4, 2e-4 + 1e-5 * float(br.grad.abs().max()), "gb")
         if cin > 1:
             close(nc(e.G[id(xd)]), xr.grad, 1e-4, 1e-5, "gx")
     else:
