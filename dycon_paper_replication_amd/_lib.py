@@ -23,6 +23,7 @@ SIGNATURES = {
     "dycon_last_error": (C.c_char_p, []),
     "dycon_bfrag_bytes": (Z, [I, I, I, I]),
     "dycon_pack_bfrag": (I, [P, P, I, I, I, I, I, L, L, L, L, I, P]),
+    "dycon_pack_batch": (I, [P, I, I, P]),
     "dycon_pack_tcn": (I, [P, P, I, I, I, I, L, L, L, L, I, P]),
     "dycon_conv_gemm_workspace": (Z, [I, I, I, I, I, I, I, I, I]),
     "dycon_conv_gemm": (I, [P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, P, Z, P]),

@@ -91,6 +91,41 @@ __global__ void pack_tcn_kernel(const float* __restrict__ w, float* __restrict__
     }
 }
 
+// all weight packs of a step in ONE launch: jobs[] lives in device memory (built once; pointers are stable arena views)
+__global__ __launch_bounds__(256) void pack_batch_kernel(const dycon_pack_job_t* __restrict__ jobs) {
+    const dycon_pack_job_t jb = jobs[blockIdx.y];
+    const int G = jb.kind == 0 ? 8 : 4, KC = jb.kind == 0 ? 32 : 16;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < jb.total; i += (long long)gridDim.x * 256) {
+        float v = 0.f;
+        if (jb.kind == 2) {          // plain fp32 [T][Cin][N]
+            const int n = (int)(i % jb.N);
+            const long long q = i / jb.N;
+            const int c = (int)(q % jb.Cin);
+            int t = (int)(q / jb.Cin);
+            if (jb.flip) t = jb.T - 1 - t;
+            v = jb.w[t * jb.s_t + c * jb.s_c + (long long)(n / jb.N0) * jb.s_n1 + (long long)(n % jb.N0) * jb.s_n0];
+            ((float*)jb.out)[i] = v;
+            continue;
+        }
+        const int e = (int)(i % G);
+        long long q = i / G;
+        const int lane = (int)(q % 64);
+        q /= 64;
+        const int nt = (int)(q % jb.NT);
+        const int kc = (int)(q / jb.NT);
+        const int k = kc * KC + G * (lane >> 4) + e;
+        const int n = nt * 16 + (lane & 15);
+        if (k < jb.T * jb.Cin && n < jb.N) {
+            int t = k / jb.Cin;
+            const int c = k - t * jb.Cin;
+            if (jb.flip) t = jb.T - 1 - t;
+            v = jb.w[t * jb.s_t + c * jb.s_c + (long long)(n / jb.N0) * jb.s_n1 + (long long)(n % jb.N0) * jb.s_n0];
+        }
+        if (jb.kind == 0) ((bf16*)jb.out)[i] = __float2bfloat16(v);
+        else ((float*)jb.out)[i] = v;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // MFMA gather-GEMM
 // ------------------------------------------------------------------------------------------------
@@ -914,6 +949,13 @@ static SplitK splitk_plan(int dtype, int mode, int scatter, long long M, int N, 
     p.kc_per_split = (int)((nKC + s - 1) / s);
     p.splits = (nKC + p.kc_per_split - 1) / p.kc_per_split;
     return p;
+}
+
+extern "C" int dycon_pack_batch(const dycon_pack_job_t* jobs_dev, int njobs, int blocks_per_job, dycon_stream_t stream) {
+    DYCON_REQUIRE(jobs_dev && njobs > 0 && njobs <= 65535 && blocks_per_job > 0, "pack_batch: bad arguments");
+    pack_batch_kernel<<<dim3(blocks_per_job, njobs), 256, 0, stream>>>(jobs_dev);
+    DYCON_LAUNCH_CHECK();
+    return DYCON_OK;
 }
 
 template <typename T, int MODE, bool SC>

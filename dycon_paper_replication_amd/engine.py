@@ -141,6 +141,7 @@ class Engine:
         self.dtype, self.scale_factor, self.normalization = dtype, scale_factor, normalization
         self.gen = 0                 # bump whenever parameter values change (invalidates packed weights)
         self._packed = {}
+        self._jobs, self._jobs_dev, self._packed_gen = [], None, -1
         self.tape = []
         self.G = {}
 
@@ -148,13 +149,38 @@ class Engine:
     def params_changed(self):
         self.gen += 1
 
-    def _pk(self, key, fn):
+    def _pk(self, key, kind, w, T, Cin, N, N0, s_t, s_c, s_n1, s_n0, flip=False):
+        """Packed operand for ``key`` (kind "frag": MFMA B fragments in the compute dtype; "tcn": plain fp32).
+        The first request packs on the spot and registers a job; later generations are refreshed by repack()
+        (one launch for every registered job) or, if that was not called, lazily here."""
         hit = self._packed.get(key)
         if hit is not None and hit[0] == self.gen:
             return hit[1]
-        buf = fn(hit[1] if hit is not None else None)
+        buf = hit[1] if hit is not None else None
+        if kind == "frag":
+            buf = ops.pack_bfrag(w, self.dtype, T, Cin, N, N0, s_t, s_c, s_n1, s_n0, flip, out=buf)
+            code = 0 if self.dtype == torch.bfloat16 else 1
+        else:
+            buf = ops.pack_tcn(w, T, Cin, N, N0, s_t, s_c, s_n1, s_n0, flip, out=buf)
+            code = 2
+        if hit is None:
+            self._jobs.append((key, ops.pack_job(w, buf, code, T, Cin, N, N0, s_t, s_c, s_n1, s_n0, flip)))
+            self._jobs_dev = None
         self._packed[key] = (self.gen, buf)
         return buf
+
+    def repack(self):
+        """Refresh every registered packed operand in one launch (call after the parameters changed)."""
+        if not self._jobs or self._packed_gen == self.gen:
+            return
+        if self._jobs_dev is None:
+            first = next(iter(self._packed.values()))[1]
+            self._jobs_dev = ops.upload_pack_jobs([j for _, j in self._jobs], first.device)
+        biggest = max(j[6] for _, j in self._jobs)                    # output elements of the largest job
+        ops.pack_batch(self._jobs_dev, len(self._jobs), max(1, min(512, (biggest + 2047) // 2048)))
+        for key, _ in self._jobs:
+            self._packed[key] = (self.gen, self._packed[key][1])
+        self._packed_gen = self.gen
 
     # ---------------------------------------------------------------- gradient bookkeeping
     def _take(self, t):
@@ -181,17 +207,17 @@ class Engine:
         first_lds = (kind == "k3" and Cin == 1 and dtype == torch.bfloat16 and Cout % 16 == 0 and out_dtype == dtype
                      and x.shape[1] * x.shape[2] * x.shape[3] >= 13824)
         if first_lds:   # first layer on the matrix cores: weights packed as 16 aliased channels (stride 0), see dycon_hip.h
-            wf = self._pk((name, "f1"), lambda o: ops.pack_bfrag(w, dtype, 27, 16, Cout, Cout, 1, 0, 0, 27, out=o))
+            wf = self._pk((name, "f1"), "frag", w, 27, 16, Cout, Cout, 1, 0, 0, 27)
             y = ops.conv_gemm(x, wf, b, CONV_K3, Cout, Cout)
         elif skinny:
             assert kind in ("k3", "1x1"), "skinny path only for the first conv and the 1x1 heads"
-            wt = self._pk((name, "tcn"), lambda o: ops.pack_tcn(w, T, Cin, Cout, Cout, 1, T, 0, Cin * T, out=o))
+            wt = self._pk((name, "tcn"), "tcn", w, T, Cin, Cout, Cout, 1, T, 0, Cin * T)
             y = ops.conv_direct(x, wt, b, mode, Cout, out_dtype)
         elif kind == "deconv":
-            wf = self._pk((name, "f"), lambda o: ops.pack_bfrag(w, dtype, 1, Cin, 8 * Cout, Cout, 0, Cout * 8, 1, 8, out=o))
+            wf = self._pk((name, "f"), "frag", w, 1, Cin, 8 * Cout, Cout, 0, Cout * 8, 1, 8)
             y = ops.conv_gemm(x, wf, b, CONV_1X1, 8 * Cout, Cout, scatter=True)
         else:
-            wf = self._pk((name, "f"), lambda o: ops.pack_bfrag(w, dtype, T, Cin, Cout, Cout, 1, T, 0, Cin * T, out=o))
+            wf = self._pk((name, "f"), "frag", w, T, Cin, Cout, Cout, 1, T, 0, Cin * T)
             y = ops.conv_gemm(x, wf, b, mode, Cout, Cout)
 
         if self.recording:
@@ -207,19 +233,19 @@ class Engine:
                     return
                 cur = self.G.get(id(x))
                 if skinny:             # 1x1 head: gx[m,ci] = sum_co gy[m,co] W[co][ci]
-                    wd = self._pk((name, "tcn_d"), lambda o: ops.pack_tcn(w, 1, Cout, Cin, Cin, 0, Cin, 0, 1, out=o))
+                    wd = self._pk((name, "tcn_d"), "tcn", w, 1, Cout, Cin, Cin, 0, Cin, 0, 1)
                     gx = ops.conv_direct(gy, wd, None, CONV_1X1, Cin, x.dtype, out=cur, accumulate=cur is not None)
                 elif kind == "k3":     # conv with flipped taps and transposed channels
-                    wd = self._pk((name, "d"), lambda o: ops.pack_bfrag(w, dtype, 27, Cout, Cin, Cin, 1, Cin * 27, 0, 27, flip=True, out=o))
+                    wd = self._pk((name, "d"), "frag", w, 27, Cout, Cin, Cin, 1, Cin * 27, 0, 27, flip=True)
                     gx = ops.conv_gemm(gy, wd, None, CONV_K3, Cin, Cin, out=cur, accumulate=cur is not None)
                 elif kind == "k2s2":   # scatter: gx[2m+t, ci] = sum_co gy[m,co] W[co][ci][t]
-                    wd = self._pk((name, "d"), lambda o: ops.pack_bfrag(w, dtype, 1, Cout, 8 * Cin, Cin, 0, Cin * 8, 1, 8, out=o))
+                    wd = self._pk((name, "d"), "frag", w, 1, Cout, 8 * Cin, Cin, 0, Cin * 8, 1, 8)
                     gx = ops.conv_gemm(gy, wd, None, CONV_1X1, 8 * Cin, Cin, scatter=True, out=cur, accumulate=cur is not None)
                 elif kind == "deconv":  # gather: gx[m, ci] = sum_{t,co} gy[2m+t,co] W[ci][co][t]
-                    wd = self._pk((name, "d"), lambda o: ops.pack_bfrag(w, dtype, 8, Cout, Cin, Cin, 1, 8, 0, Cout * 8, out=o))
+                    wd = self._pk((name, "d"), "frag", w, 8, Cout, Cin, Cin, 1, 8, 0, Cout * 8)
                     gx = ops.conv_gemm(gy, wd, None, CONV_K2S2, Cin, Cin, out=cur, accumulate=cur is not None)
                 else:                  # 1x1
-                    wd = self._pk((name, "d"), lambda o: ops.pack_bfrag(w, dtype, 1, Cout, Cin, Cin, 0, Cin, 0, 1, out=o))
+                    wd = self._pk((name, "d"), "frag", w, 1, Cout, Cin, Cin, 0, Cin, 0, 1)
                     gx = ops.conv_gemm(gy, wd, None, CONV_1X1, Cin, Cin, out=cur, accumulate=cur is not None)
                 self.G[id(x)] = gx
             self.tape.append(bwd)

@@ -99,6 +99,26 @@ def pack_tcn(w: torch.Tensor, T, Cin, N, N0, s_t, s_c, s_n1, s_n0, flip=False, o
     return out
 
 
+PACK_JOB_DTYPE = [("w", "<u8"), ("out", "<u8"), ("s_t", "<i8"), ("s_c", "<i8"), ("s_n1", "<i8"), ("s_n0", "<i8"), ("total", "<i8"),
+                  ("kind", "<i4"), ("T", "<i4"), ("Cin", "<i4"), ("N", "<i4"), ("N0", "<i4"), ("flip", "<i4"), ("NT", "<i4"), ("pad_", "<i4")]
+
+
+def pack_job(w, out, kind, T, Cin, N, N0, s_t, s_c, s_n1, s_n0, flip):
+    """One dycon_pack_job_t as a tuple (kind: 0 bf16 fragments, 1 fp32 fragments, 2 plain fp32 [T][Cin][N])."""
+    return (w.data_ptr(), out.data_ptr(), s_t, s_c, s_n1, s_n0, out.numel(), kind, T, Cin, N, N0, int(flip), (N + 15) // 16, 0)
+
+
+def upload_pack_jobs(jobs, device):
+    import numpy as np
+    arr = np.array(jobs, dtype=np.dtype(PACK_JOB_DTYPE))
+    assert arr.dtype.itemsize == 88
+    return torch.from_numpy(arr.view(np.uint8).copy()).to(device)
+
+
+def pack_batch(jobs_dev, njobs, blocks_per_job=8):
+    call("dycon_pack_batch", _p(jobs_dev), njobs, blocks_per_job, _s())
+
+
 # ------------------------------------------------------------------ conv family
 def conv_gemm(x, wfrag, bias, mode, N, Cout, scatter=False, out=None, accumulate=False):
     B, D, H, W, Cin = x.shape

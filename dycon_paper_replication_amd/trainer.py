@@ -163,6 +163,8 @@ class DyconTrainer:
         if t_drop is None:
             t_drop = DropoutSpec("philox", seed=seed, offset=(2 * it + 1) << 42) if c.teacher_mode == "train" else DropoutSpec("off")
 
+        self.s_eng.repack()          # all weight packs of the step (student fwd + dgrad, teacher fwd): one launch each
+        self.t_eng.repack()
         x = volume.reshape(B, D, H, W, 1) if volume.is_contiguous() else volume.contiguous().reshape(B, D, H, W, 1)
         x_t = ops.add_noise(x, None if noise is None else noise.contiguous(), 0.1, 0.2, seed ^ 0x5DEECE66D, it << 32)  # :301-302
 

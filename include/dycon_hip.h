@@ -51,6 +51,16 @@ size_t dycon_bfrag_bytes(int dtype, int T, int Cin, int N);
 int dycon_pack_bfrag(const float* w, void* out, int dtype, int T, int Cin, int N, int N0,
                      long long s_t, long long s_c, long long s_n1, long long s_n0, int flip_taps,
                      dycon_stream_t stream);
+/* Batched form: every pack of a training step in one launch.  jobs_dev is a DEVICE array of njobs descriptors
+ * (built once -- the parameter arenas and packed buffers keep their addresses).  kind: 0 = bf16 fragments,
+ * 1 = fp32 fragments, 2 = plain fp32 [T][Cin][N]; total = number of output elements; NT = ceil(N/16). */
+typedef struct {
+    const float* w;
+    void* out;
+    long long s_t, s_c, s_n1, s_n0, total;
+    int kind, T, Cin, N, N0, flip, NT, pad_;
+} dycon_pack_job_t;
+int dycon_pack_batch(const dycon_pack_job_t* jobs_dev, int njobs, int blocks_per_job, dycon_stream_t stream);
 /* plain fp32 [T][Cin][N] packing for the skinny (Cin<8 or N%16!=0) direct kernels */
 int dycon_pack_tcn(const float* w, float* out, int T, int Cin, int N, int N0, long long s_t,
                    long long s_c, long long s_n1, long long s_n0, int flip_taps, dycon_stream_t stream);
