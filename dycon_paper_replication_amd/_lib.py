@@ -56,7 +56,7 @@ SIGNATURES = {
     "dycon_l2norm_fwd": (I, [P, P, P, I, L, I, F, P]),
     "dycon_l2norm_bwd": (I, [P, P, P, P, I, L, I, F, P]),
     "dycon_mask_pool": (I, [P, I, P, I, I, I, I, I, I, I, P]),
-    "dycon_fecl_workspace": (Z, [I, I]),
+    "dycon_fecl_workspace": (Z, [I, I, I]),
     "dycon_fecl_fwd": (I, [P, P, P, P, I, I, I, I, F, F, I, F, F, P, P, P, Z, P]),
     "dycon_fecl_finalize": (I, [P, C.c_double, F, I, P, P]),
     "dycon_set_scalars": (I, [P, I, F, F, F, F, F, F, F, F, P]),

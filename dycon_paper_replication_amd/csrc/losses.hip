@@ -377,7 +377,9 @@ __global__ __launch_bounds__(256) void fecl_kernel(const T* __restrict__ F, cons
                                                    const float* __restrict__ mask, const float* __restrict__ gamb, int N, int Dm,
                                                    float tau, float gamma, int focal, float thr, float* __restrict__ ws,
                                                    double* __restrict__ out, const float* __restrict__ coef, float lambda_cross,
-                                                   T* __restrict__ GF, int Btot) {
+                                                   float* __restrict__ GS, int Btot, int CS, int tiles_per_split) {
+    // blockIdx.z = column split: this workgroup walks column tiles [z*tiles_per_split, (z+1)*tiles_per_split) and writes
+    // its PARTIAL row results into slab z; consumers combine the CS slabs on load (max / ordered sum): deterministic.
     typedef typename FeclTile<T>::E E;
     constexpr int KS = FeclTile<T>::KS;
     constexpr bool FAST = sizeof(T) == 2;
@@ -392,11 +394,14 @@ __global__ __launch_bounds__(256) void fecl_kernel(const T* __restrict__ F, cons
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 15, kg = lane >> 4;
     const long long BN = (long long)Btot * N;
-    float* wm = ws;            // m_i
-    float* wn = ws + BN;       // n_i
-    float* wc = ws + 2 * BN;   // cnt_i
-    float* wk = ws + 3 * BN;   // kappa_i = u_i / (cnt_i - 1 + 1e-18)
-    float* wh = ws + 4 * BN;   // kappa_i * H_i
+    const int cs = blockIdx.z;
+    float* wm = ws;                          // [CS][BN] partial column max
+    float* wn = ws + (long long)CS * BN;     // [CS][BN] partial negative sums
+    float* wc = ws + 2LL * CS * BN;          // [CS][BN] partial same-class counts
+    float* wh = ws + 3LL * CS * BN;          // [CS][BN] partial kappa_i * H_i
+    float* wk = ws + 4LL * CS * BN;          // [BN]     kappa_i = u_i / (cnt_i - 1 + 1e-18)
+    auto ld_max = [&](const float* base, long long idx) { float v = base[idx]; for (int z = 1; z < CS; ++z) v = fmaxf(v, base[z * BN + idx]); return v; };
+    auto ld_sum = [&](const float* base, long long idx) { float v = base[idx]; for (int z = 1; z < CS; ++z) v += base[z * BN + idx]; return v; };
     const T* Fb = F + (long long)b * N * Dm;
     const T* Tb = Tch ? Tch + (long long)b * N * Dm : nullptr;
     const float* mb = mask + (long long)b * N;
@@ -414,9 +419,9 @@ __global__ __launch_bounds__(256) void fecl_kernel(const T* __restrict__ F, cons
         vi[i] = gi[i] < N;
         mrow[i] = vi[i] ? mb[gi[i]] : -1.f;
         mi[i] = nrow[i] = krow[i] = hrow[i] = 0.f;
-        if (PASS >= 2 && vi[i]) mi[i] = wm[rb + gi[i]];
-        if (PASS >= 3 && vi[i]) nrow[i] = wn[rb + gi[i]];
-        if (PASS >= 4 && vi[i]) { krow[i] = wk[rb + gi[i]]; hrow[i] = wh[rb + gi[i]]; }
+        if (PASS >= 2 && vi[i]) mi[i] = ld_max(wm, rb + gi[i]);
+        if (PASS >= 3 && vi[i]) nrow[i] = ld_sum(wn, rb + gi[i]);
+        if (PASS >= 4 && vi[i]) { krow[i] = wk[rb + gi[i]]; hrow[i] = ld_sum(wh, rb + gi[i]); }
     }
     float a0[4] = {0.f, 0.f, 0.f, 0.f}, a1[4] = {0.f, 0.f, 0.f, 0.f};   // per-row accumulators of the pass
     float cnum = 0.f, ccnt = 0.f;
@@ -435,7 +440,8 @@ __global__ __launch_bounds__(256) void fecl_kernel(const T* __restrict__ F, cons
         cross_scale = Tb ? coef[0] * lambda_cross / ((float)out[2] + 1e-18f) : 0.f;
     }
 
-    for (int j0 = 0; j0 < N; j0 += FT) {
+    const int j_beg = cs * tiles_per_split * FT, j_end = min(N, (cs + 1) * tiles_per_split * FT);
+    for (int j0 = j_beg; j0 < j_end; j0 += FT) {
         __syncthreads();
         stage_rows(Fj, stride, Dp, Fb, j0, N, Dm);
         __syncthreads();
@@ -455,7 +461,7 @@ __global__ __launch_bounds__(256) void fecl_kernel(const T* __restrict__ F, cons
             for (int j = 0; j < 4; ++j) {
                 const int gj = j0 + 16 * j + r;
                 if (gj >= N) continue;
-                const float mj = wm[rb + gj], mk = mb[gj];
+                const float mj = ld_max(wm, rb + gj), mk = mb[gj];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     if (mk == mrow[i]) a1[i] += 1.f;
@@ -467,7 +473,7 @@ __global__ __launch_bounds__(256) void fecl_kernel(const T* __restrict__ F, cons
             for (int j = 0; j < 4; ++j) {
                 const int gj = j0 + 16 * j + r;
                 if (gj >= N) continue;
-                const float mj = wm[rb + gj], mk = mb[gj];
+                const float mj = ld_max(wm, rb + gj), mk = mb[gj];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     if (mk == mrow[i]) {
@@ -489,8 +495,8 @@ __global__ __launch_bounds__(256) void fecl_kernel(const T* __restrict__ F, cons
             for (int j = 0; j < 4; ++j) {
                 const int gj = j0 + 16 * j + r;
                 const bool vj = gj < N;
-                const float mj = vj ? wm[rb + gj] : 0.f, mk = vj ? mb[gj] : -2.f;
-                const float nj = vj ? wn[rb + gj] : 0.f, kj = vj ? wk[rb + gj] : 0.f, hj = vj ? wh[rb + gj] : 0.f;
+                const float mj = vj ? ld_max(wm, rb + gj) : 0.f, mk = vj ? mb[gj] : -2.f;
+                const float nj = vj ? ld_sum(wn, rb + gj) : 0.f, kj = vj ? wk[rb + gj] : 0.f, hj = vj ? ld_sum(wh, rb + gj) : 0.f;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     float tv = 0.f;
@@ -550,24 +556,24 @@ __global__ __launch_bounds__(256) void fecl_kernel(const T* __restrict__ F, cons
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const float v = row16_max(a0[i]);
-            if (r == 0 && vi[i]) wm[rb + gi[i]] = v;
+            if (r == 0 && vi[i]) wm[cs * BN + rb + gi[i]] = v;
         }
     } else if (PASS == 2) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const float ns = row16_sum(a0[i]), cs = row16_sum(a1[i]);
-            if (r == 0 && vi[i]) { wn[rb + gi[i]] = ns; wc[rb + gi[i]] = cs; }
+            const float ns = row16_sum(a0[i]), cs_ = row16_sum(a1[i]);
+            if (r == 0 && vi[i]) { wn[cs * BN + rb + gi[i]] = ns; wc[cs * BN + rb + gi[i]] = cs_; }
         }
     } else if (PASS == 3) {
         float lsum = 0.f;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const float ph = row16_sum(a0[i]), cs = row16_sum(a1[i]), hs = row16_sum(hrow[i]);
+            const float ph = row16_sum(a0[i]), hs = row16_sum(hrow[i]);
             if (r == 0 && vi[i]) {
                 const float u = gamb ? gamb[rb + gi[i]] : 1.f;
-                const float kap = u / (cs - 1.f + 1e-18f);
-                wk[rb + gi[i]] = kap;
-                wh[rb + gi[i]] = kap * hs;
+                const float kap = u / (ld_sum(wc, rb + gi[i]) - 1.f + 1e-18f);   // total same-class count from pass 2
+                if (cs == 0) wk[rb + gi[i]] = kap;
+                wh[cs * BN + rb + gi[i]] = kap * hs;
                 lsum += ph * kap;
             }
         }
@@ -579,7 +585,7 @@ __global__ __launch_bounds__(256) void fecl_kernel(const T* __restrict__ F, cons
             if (Tb) { atomicAdd(&out[1], (double)bn); atomicAdd(&out[2], (double)bc); }
         }
     } else {
-        T* gb = GF + (long long)b * N * Dm;
+        float* gb = GS + ((long long)cs * Btot + b) * N * Dm;   // fp32 slab of this column split
 #pragma unroll
         for (int t = 0; t < MAXNT; ++t) {
             if (t >= ntile) continue;
@@ -587,8 +593,18 @@ __global__ __launch_bounds__(256) void fecl_kernel(const T* __restrict__ F, cons
             if (d >= Dm) continue;
 #pragma unroll
             for (int i = 0; i < 4; ++i)
-                if (vi[i]) stf(gb + (long long)gi[i] * Dm + d, gacc[t][i]);
+                if (vi[i]) gb[(long long)gi[i] * Dm + d] = gacc[t][i];
         }
+    }
+}
+
+// g_feat = sum over the column-split slabs (ordered)
+template <typename T>
+__global__ void fecl_combine_kernel(const float* __restrict__ GS, int CS, long long n, T* __restrict__ GF) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        float v = GS[i];
+        for (int z = 1; z < CS; ++z) v += GS[z * n + i];
+        stf(GF + i, v);
     }
 }
 
@@ -675,7 +691,22 @@ extern "C" int dycon_mask_pool(const void* labels, int label_bytes, float* mask,
     return DYCON_OK;
 }
 
-extern "C" size_t dycon_fecl_workspace(int B, int N) { return (size_t)5 * B * N * sizeof(float); }
+// column splits: enough workgroups to occupy the chip twice over (LDS allows 2 per CU)
+static void fecl_split(int B, int N, int& CS, int& tps) {
+    const int nct = (N + FT - 1) / FT;
+    long long want = (512 + (long long)nct * B - 1) / ((long long)nct * B);
+    if (want > 8) want = 8;
+    if (want > nct) want = nct;
+    if (want < 1) want = 1;
+    tps = (nct + (int)want - 1) / (int)want;
+    CS = (nct + tps - 1) / tps;
+}
+
+extern "C" size_t dycon_fecl_workspace(int B, int N, int Dm) {
+    int CS, tps;
+    fecl_split(B, N, CS, tps);
+    return ((size_t)(4 * CS + 1) * B * N + (size_t)CS * B * N * Dm) * sizeof(float);
+}
 
 template <typename T> static size_t fecl_lds_bytes(int Dm, bool grad) {
     typedef FeclTile<T> G;
@@ -687,16 +718,19 @@ template <typename T> static size_t fecl_lds_bytes(int Dm, bool grad) {
 template <typename T, int PASS>
 static int fecl_launch(const void* feat, const void* teacher, const float* mask, const float* gamb, int B, int N, int Dm,
                        float tau, float gamma, int focal, float thr, float* ws, double* out, const float* coef, float lambda_cross,
-                       void* gf, dycon_stream_t stream) {
+                       dycon_stream_t stream) {
     const size_t lds = fecl_lds_bytes<T>(Dm, PASS == 4);
     // > 64 KiB of dynamic LDS needs the opt-in attribute (idempotent, no sync, capture-safe)
     if (hipFuncSetAttribute((const void*)fecl_kernel<T, PASS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
         dycon_set_error("fecl: cannot reserve %zu bytes of LDS", lds);
         return DYCON_ERR_LAUNCH;
     }
-    dim3 grid(cdiv(N, FT), B);
+    int CS, tps;
+    fecl_split(B, N, CS, tps);
+    float* gslab = ws + (size_t)(4 * CS + 1) * B * N;
+    dim3 grid(cdiv(N, FT), B, CS);
     fecl_kernel<T, PASS><<<grid, 256, lds, stream>>>((const T*)feat, (const T*)teacher, mask, gamb, N, Dm, tau, gamma, focal, thr, ws,
-                                                    out, coef, lambda_cross, (T*)gf, B);
+                                                    out, coef, lambda_cross, gslab, B, CS, tps);
     DYCON_LAUNCH_CHECK();
     return DYCON_OK;
 }
@@ -705,7 +739,7 @@ static int fecl_check(const char* who, const void* feat, const float* mask, int 
     DYCON_REQUIRE(feat && mask && B > 0 && N > 0 && Dm > 0 && tau > 0.f, "%s: bad arguments", who);
     DYCON_REQUIRE(Dm <= 256, "%s: feature dim %d > 256 not supported", who, Dm);
     DYCON_REQUIRE(B <= 65535, "%s: batch too large", who);
-    DYCON_REQUIRE(ws_bytes >= dycon_fecl_workspace(B, N), "%s: workspace too small", who);
+    DYCON_REQUIRE(ws_bytes >= dycon_fecl_workspace(B, N, Dm), "%s: workspace too small", who);
     return DYCON_OK;
 }
 
@@ -719,9 +753,9 @@ extern "C" int dycon_fecl_fwd(const void* feat, const void* teacher, const float
     if (hipMemsetAsync(out, 0, 4 * sizeof(double), stream) != hipSuccess) { dycon_set_error("fecl_fwd: memset failed"); return DYCON_ERR_LAUNCH; }
     int e = DYCON_OK;
     DYCON_DISPATCH(dtype, {
-        e = fecl_launch<T, 1>(feat, nullptr, mask, gambling, B, N, Dm, temperature, gamma, focal, cross_thresh, workspace, out, nullptr, lambda_cross, nullptr, stream);
-        if (!e) e = fecl_launch<T, 2>(feat, nullptr, mask, gambling, B, N, Dm, temperature, gamma, focal, cross_thresh, workspace, out, nullptr, lambda_cross, nullptr, stream);
-        if (!e) e = fecl_launch<T, 3>(feat, teacher, mask, gambling, B, N, Dm, temperature, gamma, focal, cross_thresh, workspace, out, nullptr, lambda_cross, nullptr, stream);
+        e = fecl_launch<T, 1>(feat, nullptr, mask, gambling, B, N, Dm, temperature, gamma, focal, cross_thresh, workspace, out, nullptr, lambda_cross, stream);
+        if (!e) e = fecl_launch<T, 2>(feat, nullptr, mask, gambling, B, N, Dm, temperature, gamma, focal, cross_thresh, workspace, out, nullptr, lambda_cross, stream);
+        if (!e) e = fecl_launch<T, 3>(feat, teacher, mask, gambling, B, N, Dm, temperature, gamma, focal, cross_thresh, workspace, out, nullptr, lambda_cross, stream);
     });
     if (e) return e;
     fecl_finalize_kernel<<<1, 1, 0, stream>>>(out, (double)B * N, lambda_cross, teacher != nullptr, loss);
@@ -747,7 +781,15 @@ extern "C" int dycon_fecl_bwd(const void* feat, const void* teacher, const float
     int e = DYCON_OK;
     DYCON_DISPATCH(dtype, {
         e = fecl_launch<T, 4>(feat, teacher, mask, gambling, B, N, Dm, temperature, gamma, focal, cross_thresh, workspace,
-                              const_cast<double*>(out), coef, lambda_cross, g_feat, stream);
+                              const_cast<double*>(out), coef, lambda_cross, stream);
+        if (!e) {
+            int CS, tps;
+            fecl_split(B, N, CS, tps);
+            const long long n = (long long)B * N * Dm;
+            fecl_combine_kernel<T><<<lgrid(n), 256, 0, stream>>>(workspace + (size_t)(4 * CS + 1) * B * N, CS, n, (T*)g_feat);
+        }
     });
-    return e;
+    if (e) return e;
+    DYCON_LAUNCH_CHECK();
+    return DYCON_OK;
 }

@@ -380,7 +380,7 @@ def fecl_fwd(feat, teacher, mask, gambling, temperature, gamma, use_focal, cross
     st = FeclState()
     st.out = torch.empty(4, dtype=torch.float64, device=feat.device)
     st.loss = torch.empty(1, dtype=torch.float32, device=feat.device)
-    st.ws = _ws(query("dycon_fecl_workspace", B, N), feat)
+    st.ws = _ws(query("dycon_fecl_workspace", B, N, Dm), feat)
     call("dycon_fecl_fwd", _p(feat), _p(teacher), _p(mask), _p(gambling), dt(feat), B, N, Dm, temperature, gamma,
          int(use_focal), cross_thresh, lambda_cross, _p(st.out), _p(st.loss), _p(st.ws), st.ws.numel() * 4, _s())
     return st.loss, st

@@ -202,10 +202,11 @@ int dycon_mask_pool(const void* labels, int label_bytes, float* mask, int B, int
 
 /* ---------------------------------------------------------------- FeCL (utils/dycon_losses.py:150-235)
  * Blockwise: the (B,N,N) similarity matrix is never materialised; Gram tiles are recomputed on
- * MFMA in each of the passes.  feat/teacher: (B,N,Dm) L2-normalised rows; mask: (B,N) float.
+ * MFMA in each of the passes.  Columns are split over workgroups (partial row results in slabs,
+ * combined in order on load): deterministic, and enough workgroups to fill the chip at N = 1728.  feat/teacher: (B,N,Dm) L2-normalised rows; mask: (B,N) float.
  * out (device, 4 doubles, zeroed by the call): student_sum, cross_num, cross_cnt, unused.
  * loss[0] (device float) = student_sum/(B*N) + lambda_cross*cross_num/(cross_cnt+1e-18). */
-size_t dycon_fecl_workspace(int B, int N);
+size_t dycon_fecl_workspace(int B, int N, int Dm);
 int dycon_fecl_fwd(const void* feat, const void* teacher, const float* mask, const float* gambling,
                    int dtype, int B, int N, int Dm, float temperature, float gamma, int use_focal,
                    float cross_thresh, float lambda_cross, double* out, float* loss, float* workspace,

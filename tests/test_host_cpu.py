@@ -31,7 +31,7 @@ def test_abi_surface_matches_header():
     # pure host-side queries are callable without a GPU
     assert lib.dycon_bfrag_bytes(_lib.BF16, 27, 16, 16) == 14 * 1 * 64 * 16
     assert lib.dycon_bfrag_bytes(_lib.F32, 27, 16, 16) == 27 * 1 * 64 * 16
-    assert lib.dycon_fecl_workspace(4, 1728) == 5 * 4 * 1728 * 4
+    assert lib.dycon_fecl_workspace(4, 1728, 256) >= 5 * 4 * 1728 * 4
     assert lib.dycon_conv_gemm_workspace(_lib.BF16, _lib.CONV_K3, 0, 4, 96, 96, 96, 16, 16) == 0       # big level: no split-K
     assert lib.dycon_conv_gemm_workspace(_lib.BF16, _lib.CONV_K3, 0, 4, 6, 6, 6, 256, 256) > 0        # 6^3 level: split-K slabs
 
