@@ -677,6 +677,133 @@ __global__ __launch_bounds__(256, 2) void wgrad_k3_bf16_kernel(const bf16* __res
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// k=2 / stride-2 weight gradient on the bf16 matrix cores (down-convolutions and, with the operand roles swapped,
+// transposed convolutions):   dW[t][c_hi][c_lo] = sum_m  HI[2m + t][c_hi] * LO[m][c_lo],   t = 2x2x2 taps.
+// Same structure as wgrad_k3_bf16_kernel: natural-order LDS tiles, transposed ds_read_b64_tr_b16 fragments;
+// a 4x4x8 tile of LO voxels meets its 8x8x16 block of HI voxels (no halo); the four waves own two taps each.
+// ------------------------------------------------------------------------------------------------
+template <int NT>
+__global__ __launch_bounds__(256, 2) void wgrad_k2s2_bf16_kernel(const bf16* __restrict__ HI, const bf16* __restrict__ LO,
+                                                                 float* __restrict__ part, float* __restrict__ bias_part, int B,
+                                                                 int d, int h, int w, int Chi, int Clo, int nCoBlk, int nTiles,
+                                                                 int tilesZ, int tilesY, int tilesX) {
+    constexpr int CB = 16 * NT;
+    constexpr int HZ = 2 * WG_TZ, HY = 2 * WG_TY, HX = 2 * WG_TX;     // 8 x 8 x 16 HI voxels
+    constexpr int NHI = HZ * HY * HX;                                   // 1024
+    __shared__ __attribute__((aligned(16))) unsigned short Xh[NHI * 16];
+    __shared__ __attribute__((aligned(16))) unsigned short Gt[WG_NV * CB];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int kg = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
+    const int ci0 = (blockIdx.x / nCoBlk) * 16;
+    const int co0 = (blockIdx.x % nCoBlk) * CB;
+    const int D = 2 * d, H = 2 * h, W = 2 * w;
+    f32x4 acc[2][NT];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[a][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float bsum[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) bsum[j] = 0.f;
+    const bool do_bias = bias_part != nullptr && ci0 == 0 && wave == 0;
+
+    for (int tile = blockIdx.y; tile < nTiles; tile += gridDim.y) {
+        int rr = tile;
+        const int tx = rr % tilesX; rr /= tilesX;
+        const int ty = rr % tilesY; rr /= tilesY;
+        const int tz = rr % tilesZ;
+        const int b = rr / tilesZ;
+        const int z0 = tz * WG_TZ, y0 = ty * WG_TY, x0 = tx * WG_TX;   // LO coordinates
+        __syncthreads();
+        {   // ---- HI block: 1024 voxels x 32 B, all loads in flight first
+            uint4 sx[NHI * 2 / 256];
+#pragma unroll
+            for (int it = 0; it < NHI * 2 / 256; ++it) {
+                const int e = threadIdx.x + 256 * it;
+                const int hv = e >> 1, half = e & 1;
+                const int hx = hv % HX, hy = (hv / HX) % HY, hz = hv / (HX * HY);
+                const int z = 2 * z0 + hz, y = 2 * y0 + hy, x = 2 * x0 + hx;
+                sx[it] = make_uint4(0, 0, 0, 0);
+                if (z < D && y < H && x < W)
+                    sx[it] = *reinterpret_cast<const uint4*>(HI + ((((long long)b * D + z) * H + y) * W + x) * Chi + ci0 + 8 * half);
+            }
+#pragma unroll
+            for (int it = 0; it < NHI * 2 / 256; ++it) {
+                const int e = threadIdx.x + 256 * it;
+                *reinterpret_cast<uint4*>(Xh + (e >> 1) * 16 + 8 * (e & 1)) = sx[it];
+            }
+        }
+        {   // ---- LO tile: 128 voxels x CB channels
+            constexpr int NSG = WG_NV * (CB / 8) / 256 > 0 ? WG_NV * (CB / 8) / 256 : 1;
+            uint4 sg[NSG];
+#pragma unroll
+            for (int it = 0; it < NSG; ++it) {
+                const int e = threadIdx.x + 256 * it;
+                const int v8 = e % (CB / 8), vv = e / (CB / 8);
+                const int vx = vv % WG_TX, vy = (vv / WG_TX) % WG_TY, vz = vv / (WG_TX * WG_TY);
+                const int z = z0 + vz, y = y0 + vy, x = x0 + vx;
+                sg[it] = make_uint4(0, 0, 0, 0);
+                if (e < WG_NV * (CB / 8) && z < d && y < h && x < w && co0 + 8 * v8 < Clo)
+                    sg[it] = *reinterpret_cast<const uint4*>(LO + ((((long long)b * d + z) * h + y) * w + x) * Clo + co0 + 8 * v8);
+            }
+#pragma unroll
+            for (int it = 0; it < NSG; ++it) {
+                const int e = threadIdx.x + 256 * it;
+                if (e < WG_NV * (CB / 8)) *reinterpret_cast<uint4*>(Gt + (e / (CB / 8)) * CB + 8 * (e % (CB / 8))) = sg[it];
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int row = 4 * s + kg, z = row >> 2, y = row & 3;
+            bf16x8 bfr[NT];
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const unsigned short* g0 = Gt + (row * 8 + q) * CB + 16 * j + 4 * p;
+                bfr[j] = tr_frag(g0, g0 + 4 * CB);
+                if (do_bias) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) bsum[j] += (float)bfr[j][e];
+                }
+            }
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                const int t = 2 * wave + a;
+                const int dz = t >> 2, dy = (t >> 1) & 1, dx = t & 1;
+                // HI voxel of LO voxel (z, y, x = q (+4)) : (2z+dz, 2y+dy, 2x+dx)
+                const unsigned short* a0 = Xh + (((2 * z + dz) * HY + (2 * y + dy)) * HX + 2 * q + dx) * 16 + 4 * p;
+                const bf16x8 afr = tr_frag(a0, a0 + 8 * 16);
+#pragma unroll
+                for (int j = 0; j < NT; ++j) acc[a][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr, bfr[j], acc[a][j], 0, 0, 0);
+            }
+        }
+    }
+    const int col = lane & 15;
+    float* dst = part + (long long)blockIdx.y * 8 * Chi * Clo;
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+        const int t = 2 * wave + a;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int co = co0 + 16 * j + col;
+            if (co >= Clo) continue;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) dst[((long long)t * Chi + ci0 + 4 * kg + i) * Clo + co] = acc[a][j][i];
+        }
+    }
+    if (do_bias) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            float v = bsum[j];
+            v += __shfl_xor(v, 16, 64);
+            v += __shfl_xor(v, 32, 64);
+            const int co = co0 + 16 * j + col;
+            if (kg == 0 && co < Clo) bias_part[(long long)blockIdx.y * Clo + co] = v;
+        }
+    }
+}
+
 // skinny weight gradient: thread j owns output element (t, ci, co); the block walks a voxel slice
 template <typename TX, typename TG, int MODE>
 __global__ __launch_bounds__(256) void conv_wgrad_direct_kernel(const TX* __restrict__ X, const TG* __restrict__ GY,
@@ -1130,6 +1257,25 @@ static WgradK3Plan wgrad_k3_plan(int B, int D, int H, int W, int Cin, int Cout) 
     p.splits = (int)s;
     return p;
 }
+static bool wgrad_k2_ok(int mode, int Cin, int Cout) {
+    return mode == DYCON_CONV_K2S2 && Cin % 16 == 0 && Cout % 16 == 0 && (Cout == 16 || Cout == 32 || Cout % 64 == 0);
+}
+static WgradK3Plan wgrad_k2_plan(int B, int Di, int Hi, int Wi, int Cin, int Cout) {   // tiles over the LO (half) grid
+    WgradK3Plan p;
+    p.tilesZ = cdiv(Di / 2, WG_TZ); p.tilesY = cdiv(Hi / 2, WG_TY); p.tilesX = cdiv(Wi / 2, WG_TX);
+    p.nTiles = B * p.tilesZ * p.tilesY * p.tilesX;
+    p.NT = Cout >= 64 ? 4 : Cout / 16;
+    p.nCoBlk = cdiv(Cout, 16 * p.NT);
+    p.gx = (Cin / 16) * p.nCoBlk;
+    const long long L = 8LL * Cin * Cout;
+    long long s = 2048 / p.gx;
+    const long long cap = (16LL << 20) / (4 * L);
+    if (s > cap) s = cap;
+    if (s > p.nTiles) s = p.nTiles;
+    if (s < 1) s = 1;
+    p.splits = (int)s;
+    return p;
+}
 static bool wgrad_k3_ok(int mode, int Cin, int Cout) {
     return mode == DYCON_CONV_K3 && (Cin % 16 == 0 || Cin == 1) && Cout % 16 == 0 && (Cout == 16 || Cout == 32 || Cout % 64 == 0);
 }
@@ -1137,8 +1283,8 @@ static bool wgrad_k3_ok(int mode, int Cin, int Cout) {
 extern "C" size_t dycon_conv_wgrad_workspace(int mode, int B, int Di, int Hi, int Wi, int Cin, int Cout) {
     const WgradPlan p = wgrad_plan(mode, B, Di, Hi, Wi, Cin, Cout);
     size_t need = (size_t)p.splits * p.L * sizeof(float);
-    if (wgrad_k3_ok(mode, Cin, Cout)) {
-        const WgradK3Plan k = wgrad_k3_plan(B, Di, Hi, Wi, Cin, Cout);
+    if (wgrad_k3_ok(mode, Cin, Cout) || wgrad_k2_ok(mode, Cin, Cout)) {
+        const WgradK3Plan k = mode == DYCON_CONV_K3 ? wgrad_k3_plan(B, Di, Hi, Wi, Cin, Cout) : wgrad_k2_plan(B, Di, Hi, Wi, Cin, Cout);
         const size_t n2 = ((size_t)k.splits * p.L + (size_t)k.splits * Cout) * sizeof(float);
         if (n2 > need) need = n2;
     }
@@ -1192,6 +1338,25 @@ extern "C" int dycon_conv_wgrad(const void* x, int x_dtype, const void* gy, int 
         else if (k.NT == 2) DYCON_WK3(2, false);
         else DYCON_WK3(4, false);
 #undef DYCON_WK3
+        DYCON_LAUNCH_CHECK();
+        launch_reduce_partials(workspace, k.splits, p.L, dw, Cin, Cout, s_t, s_c, s_n, stream);
+        DYCON_LAUNCH_CHECK();
+        if (dbias) {
+            launch_reduce_partials(bpart, k.splits, Cout, dbias, 1, Cout, 0, 0, 1, stream);
+            DYCON_LAUNCH_CHECK();
+        }
+        return DYCON_OK;
+    }
+    if (x_dtype == DYCON_BF16 && g_dtype == DYCON_BF16 && wgrad_k2_ok(mode, Cin, Cout)) {
+        const WgradK3Plan k = wgrad_k2_plan(B, Di, Hi, Wi, Cin, Cout);
+        float* bpart = dbias ? workspace + (size_t)k.splits * p.L : nullptr;
+        dim3 grid(k.gx, k.splits);
+#define DYCON_WK2(NTV) \
+    wgrad_k2s2_bf16_kernel<NTV><<<grid, 256, 0, stream>>>((const bf16*)x, (const bf16*)gy, workspace, bpart, B, Di / 2, Hi / 2, Wi / 2, Cin, Cout, k.nCoBlk, k.nTiles, k.tilesZ, k.tilesY, k.tilesX)
+        if (k.NT == 1) DYCON_WK2(1);
+        else if (k.NT == 2) DYCON_WK2(2);
+        else DYCON_WK2(4);
+#undef DYCON_WK2
         DYCON_LAUNCH_CHECK();
         launch_reduce_partials(workspace, k.splits, p.L, dw, Cin, Cout, s_t, s_c, s_n, stream);
         DYCON_LAUNCH_CHECK();
