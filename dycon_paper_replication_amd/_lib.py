@@ -34,6 +34,7 @@ SIGNATURES = {
     "dycon_colsum": (I, [P, I, P, L, I, P, Z, P]),
     "dycon_norm_workspace": (Z, [I, L, I]),
     "dycon_norm_stats": (I, [P, I, I, L, I, I, F, P, P, P, F, P, Z, P]),
+    "dycon_norm_fwd": (I, [P, P, I, I, L, I, I, F, P, P, P, I, P, P, P, P, F, P, Z, P]),
     "dycon_norm_apply": (I, [P, P, I, I, L, I, I, P, P, P, I, P, P, P]),
     "dycon_norm_bwd": (I, [P, I, P, P, I, I, L, I, I, P, P, P, I, P, P, P, P, Z, P]),
     "dycon_maxpool2_fwd": (I, [P, P, P, I, I, I, I, I, I, P]),

@@ -246,6 +246,198 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(const T* __restrict
 }
 
 // ------------------------------------------------------------------------------------------------
+// Small levels (V <= 2048 voxels, i.e. 12^3 and 6^3): one launch does statistics + apply (forward) or reductions + apply (backward).
+// A workgroup owns SPAN = max(cpg, 16 B worth) consecutive channels of one sample (= SPAN/cpg whole groups), walks the
+// voxels twice (second pass served by L2) and needs no inter-workgroup reduction.  Replaces 3 launches by 1 at the
+// levels where launch latency, not bandwidth, sets the time.
+// ------------------------------------------------------------------------------------------------
+template <int NV>
+__device__ __forceinline__ void block_reduce_vec(float (&v)[NV], float* sm /* [4][NV] */) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) v[k] = wave_sum(v[k]);
+    __syncthreads();
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < NV; ++k) sm[wv * NV + k] = v[k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < NV; ++k) v[k] = sm[k] + sm[NV + k] + sm[2 * NV + k] + sm[3 * NV + k];
+}
+
+template <typename T, int SPAN, int CPG>
+__global__ __launch_bounds__(256) void norm_fused_fwd_kernel(const T* __restrict__ X, T* __restrict__ Y, long long V, int C, int G,
+                                                             float eps, float* __restrict__ stats, const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, int relu, const T* __restrict__ skip,
+                                                             const float* __restrict__ chan_scale, float* running_mean,
+                                                             float* running_var, float momentum) {
+    constexpr int VN = Vec16<T>::N, NVEC = SPAN / VN;
+    __shared__ float sm[4 * 2 * SPAN];
+    constexpr int cpg = CPG;
+    const int n = blockIdx.y, c0 = blockIdx.x * SPAN;
+    const T* xp = X + (long long)n * V * C + c0;
+    float acc[2 * SPAN];
+#pragma unroll
+    for (int k = 0; k < 2 * SPAN; ++k) acc[k] = 0.f;
+    for (long long v = threadIdx.x; v < V; v += 256) {
+#pragma unroll
+        for (int q = 0; q < NVEC; ++q) {
+            const Vec16<T> x = ld16(xp + v * C + q * VN);
+#pragma unroll
+            for (int k = 0; k < VN; ++k) { const float f = x.get(k); acc[q * VN + k] += f; acc[SPAN + q * VN + k] += f * f; }
+        }
+    }
+    block_reduce_vec<2 * SPAN>(acc, sm);
+    // per-channel scale / shift (every thread computes all SPAN of them: cheap, avoids another LDS round trip)
+    float sc[SPAN], sh[SPAN], cs[SPAN];
+    const double cnt = (double)V * cpg;
+#pragma unroll
+    for (int k = 0; k < SPAN; ++k) {
+        constexpr int dummy_ = 0; (void)dummy_;
+        const int gl = k / cpg;                       // group inside the span (compile-time: registers stay statically indexed)
+        double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+        for (int j = 0; j < SPAN; ++j)
+            if (j / cpg == gl) { s0 += acc[j]; s1 += acc[SPAN + j]; }
+        const double mean = s0 / cnt;
+        double var = s1 / cnt - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+        const int c = c0 + k;
+        const float gm = gamma ? gamma[c] : 1.f, bt = beta ? beta[c] : 0.f;
+        sc[k] = rstd * gm;
+        sh[k] = bt - (float)mean * rstd * gm;
+        cs[k] = chan_scale ? chan_scale[(long long)n * C + c] : 1.f;
+        if (threadIdx.x == 0 && (k % cpg) == 0) {
+            const int g = c / cpg;
+            stats[((long long)n * G + g) * 2] = (float)mean;
+            stats[((long long)n * G + g) * 2 + 1] = rstd;
+            if (running_mean && gridDim.y == 1 && G == C) {
+                running_mean[g] = (1.f - momentum) * running_mean[g] + momentum * (float)mean;
+                const double unb = cnt > 1.0 ? var * cnt / (cnt - 1.0) : var;
+                running_var[g] = (1.f - momentum) * running_var[g] + momentum * (float)unb;
+            }
+        }
+    }
+    T* yp = Y + (long long)n * V * C + c0;
+    const T* sp = skip ? skip + (long long)n * V * C + c0 : nullptr;
+    for (long long v = threadIdx.x; v < V; v += 256) {
+#pragma unroll
+        for (int q = 0; q < NVEC; ++q) {
+            const Vec16<T> x = ld16(xp + v * C + q * VN);
+            Vec16<T> s, y;
+            if (sp) s = ld16(sp + v * C + q * VN);
+#pragma unroll
+            for (int k = 0; k < VN; ++k) {
+                float f = x.get(k) * sc[q * VN + k] + sh[q * VN + k];
+                if (relu) f = f < 0.f ? 0.f : f;
+                f *= cs[q * VN + k];
+                if (sp) f += s.get(k);
+                y.set(k, f);
+            }
+            st16(yp + v * C + q * VN, y);
+        }
+    }
+}
+
+template <typename T, int SPAN, int CPG>
+__global__ __launch_bounds__(256) void norm_fused_bwd_kernel(const T* __restrict__ X, const T* __restrict__ GY, T* __restrict__ GX,
+                                                             long long V, int C, int G, const float* __restrict__ stats,
+                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                             int relu, const float* __restrict__ chan_scale,
+                                                             float* __restrict__ dpart /* [Nb][C][2] or NULL */) {
+    constexpr int VN = Vec16<T>::N, NVEC = SPAN / VN;
+    __shared__ float sm[4 * 2 * SPAN];
+    constexpr int cpg = CPG;
+    const int n = blockIdx.y, c0 = blockIdx.x * SPAN;
+    const T* xp = X + (long long)n * V * C + c0;
+    const T* gp = GY + (long long)n * V * C + c0;
+    float mean[SPAN], rstd[SPAN], gm[SPAN], bt[SPAN], cs[SPAN];
+#pragma unroll
+    for (int k = 0; k < SPAN; ++k) {
+        const int c = c0 + k, g = c / cpg;
+        mean[k] = stats[((long long)n * G + g) * 2];
+        rstd[k] = stats[((long long)n * G + g) * 2 + 1];
+        gm[k] = gamma ? gamma[c] : 1.f;
+        bt[k] = beta ? beta[c] : 0.f;
+        cs[k] = chan_scale ? chan_scale[(long long)n * C + c] : 1.f;
+    }
+    float acc[2 * SPAN];
+#pragma unroll
+    for (int k = 0; k < 2 * SPAN; ++k) acc[k] = 0.f;
+    for (long long v = threadIdx.x; v < V; v += 256) {
+#pragma unroll
+        for (int q = 0; q < NVEC; ++q) {
+            const Vec16<T> x = ld16(xp + v * C + q * VN), gv = ld16(gp + v * C + q * VN);
+#pragma unroll
+            for (int k = 0; k < VN; ++k) {
+                const int j = q * VN + k;
+                const float xh = (x.get(k) - mean[j]) * rstd[j];
+                float g = gv.get(k) * cs[j];
+                if (relu && !(gm[j] * xh + bt[j] > 0.f)) g = 0.f;
+                acc[j] += g;
+                acc[SPAN + j] += g * xh;
+            }
+        }
+    }
+    block_reduce_vec<2 * SPAN>(acc, sm);
+    if (dpart && threadIdx.x == 0) {     // per-(n, channel) {dbeta, dgamma} contributions (static register indices)
+#pragma unroll
+        for (int k = 0; k < SPAN; ++k) {
+            float* d = dpart + ((long long)n * C + c0 + k) * 2;
+            d[0] = acc[k];
+            d[1] = acc[SPAN + k];
+        }
+    }
+    float A[SPAN], Bq[SPAN];
+    const float inv_cnt = 1.f / ((float)V * (float)cpg);
+#pragma unroll
+    for (int k = 0; k < SPAN; ++k) {
+        const int gl = k / cpg;
+        float a = 0.f, bq = 0.f;
+#pragma unroll
+        for (int j = 0; j < SPAN; ++j)
+            if (j / cpg == gl) { a += gm[j] * acc[j]; bq += gm[j] * acc[SPAN + j]; }
+        A[k] = a * inv_cnt;
+        Bq[k] = bq * inv_cnt;
+    }
+    T* op = GX + (long long)n * V * C + c0;
+    for (long long v = threadIdx.x; v < V; v += 256) {
+#pragma unroll
+        for (int q = 0; q < NVEC; ++q) {
+            const Vec16<T> x = ld16(xp + v * C + q * VN), gv = ld16(gp + v * C + q * VN);
+            Vec16<T> o;
+#pragma unroll
+            for (int k = 0; k < VN; ++k) {
+                const int j = q * VN + k;
+                const float xh = (x.get(k) - mean[j]) * rstd[j];
+                float g = gv.get(k) * cs[j];
+                if (relu && !(gm[j] * xh + bt[j] > 0.f)) g = 0.f;
+                o.set(k, rstd[j] * (gm[j] * g - (A[j] + xh * Bq[j])));
+            }
+            st16(op + v * C + q * VN, o);
+        }
+    }
+}
+
+// dgamma/dbeta[c] = sum over samples of the fused backward's per-(n, c) contributions
+__global__ void norm_sum_dparams_kernel(const float* __restrict__ dpart, int Nb, int C, float* dgamma, float* dbeta) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float s0 = 0.f, s1 = 0.f;
+    for (int n = 0; n < Nb; ++n) { s0 += dpart[((long long)n * C + c) * 2]; s1 += dpart[((long long)n * C + c) * 2 + 1]; }
+    if (dbeta) dbeta[c] = s0;
+    if (dgamma) dgamma[c] = s1;
+}
+
+static bool norm_fused_ok(int dtype, long long V, int C, int G) {
+    const int VN = dtype == DYCON_BF16 ? 8 : 4, cpg = C / G;
+    const int span = cpg > VN ? cpg : VN;
+    return V <= 2048 && (cpg & (cpg - 1)) == 0 && cpg <= 16 && C % span == 0 && (span == 4 || span == 8 || span == 16);
+}
+
+// ------------------------------------------------------------------------------------------------
 extern "C" size_t dycon_norm_workspace(int Nb, long long V, int C) {
     const NormPlan p = norm_plan(V);
     return ((size_t)Nb * p.chunks * C * 2 + (size_t)Nb * C * 2 + 64) * sizeof(float);
@@ -277,6 +469,34 @@ extern "C" int dycon_norm_stats(const void* x, int dtype, int Nb, long long V, i
     return DYCON_OK;
 }
 
+// One-launch forward for the small levels; returns DYCON_OK and sets *done = 1 when it handled the call.
+extern "C" int dycon_norm_fwd(const void* x, void* y, int dtype, int Nb, long long V, int C, int G, float eps, float* stats,
+                              const float* gamma, const float* beta, int relu, const void* skip, const float* chan_scale,
+                              float* running_mean, float* running_var, float momentum, float* workspace, size_t ws_bytes,
+                              dycon_stream_t stream) {
+    DYCON_REQUIRE(x && y && stats, "norm_fwd: null pointer");
+    if (int e = norm_check("norm_fwd", dtype, Nb, V, C, G)) return e;
+    if (norm_fused_ok(dtype, V, C, G)) {
+        const int VN = dtype == DYCON_BF16 ? 8 : 4, cpg = C / G;
+        const int span = cpg > VN ? cpg : VN;
+        dim3 grid(C / span, Nb);
+#define DYCON_NF(TT, SP, CP) norm_fused_fwd_kernel<TT, SP, CP><<<grid, 256, 0, stream>>>((const TT*)x, (TT*)y, V, C, G, eps, stats, gamma, beta, relu, (const TT*)skip, chan_scale, running_mean, running_var, momentum)
+        if (dtype == DYCON_BF16) {
+            if (cpg == 1) DYCON_NF(bf16, 8, 1); else if (cpg == 2) DYCON_NF(bf16, 8, 2); else if (cpg == 4) DYCON_NF(bf16, 8, 4);
+            else if (cpg == 8) DYCON_NF(bf16, 8, 8); else DYCON_NF(bf16, 16, 16);
+        } else {
+            if (cpg == 1) DYCON_NF(float, 4, 1); else if (cpg == 2) DYCON_NF(float, 4, 2); else if (cpg == 4) DYCON_NF(float, 4, 4);
+            else if (cpg == 8) DYCON_NF(float, 8, 8); else DYCON_NF(float, 16, 16);
+        }
+#undef DYCON_NF
+        DYCON_LAUNCH_CHECK();
+        return DYCON_OK;
+    }
+    DYCON_REQUIRE(workspace, "norm_fwd: workspace missing");
+    if (int e = dycon_norm_stats(x, dtype, Nb, V, C, G, eps, stats, running_mean, running_var, momentum, workspace, ws_bytes, stream)) return e;
+    return dycon_norm_apply(x, y, dtype, Nb, V, C, G, stats, gamma, beta, relu, skip, chan_scale, stream);
+}
+
 static int apply_grid(long long V, int C, int VN) {
     long long blocks = (V * C / VN + 256 * 4 - 1) / (256 * 4);
     if (blocks > 2048) blocks = 2048;
@@ -305,6 +525,27 @@ extern "C" int dycon_norm_bwd(const void* src, int from_y, const void* gy, void*
     DYCON_REQUIRE(src && gy && gx && stats && workspace, "norm_bwd: null pointer");
     if (int e = norm_check("norm_bwd", dtype, Nb, V, C, G)) return e;
     DYCON_REQUIRE(ws_bytes >= dycon_norm_workspace(Nb, V, C), "norm_bwd: workspace too small");
+    if (!from_y && norm_fused_ok(dtype, V, C, G)) {   // small levels: one launch (+ a tiny per-channel sum over the samples)
+        const int VN = dtype == DYCON_BF16 ? 8 : 4, cpg = C / G;
+        const int span = cpg > VN ? cpg : VN;
+        const bool want = dgamma || dbeta;
+        dim3 grid(C / span, Nb);
+#define DYCON_NB(TT, SP, CP) norm_fused_bwd_kernel<TT, SP, CP><<<grid, 256, 0, stream>>>((const TT*)src, (const TT*)gy, (TT*)gx, V, C, G, stats, gamma, beta, relu, chan_scale, want ? workspace : nullptr)
+        if (dtype == DYCON_BF16) {
+            if (cpg == 1) DYCON_NB(bf16, 8, 1); else if (cpg == 2) DYCON_NB(bf16, 8, 2); else if (cpg == 4) DYCON_NB(bf16, 8, 4);
+            else if (cpg == 8) DYCON_NB(bf16, 8, 8); else DYCON_NB(bf16, 16, 16);
+        } else {
+            if (cpg == 1) DYCON_NB(float, 4, 1); else if (cpg == 2) DYCON_NB(float, 4, 2); else if (cpg == 4) DYCON_NB(float, 4, 4);
+            else if (cpg == 8) DYCON_NB(float, 8, 8); else DYCON_NB(float, 16, 16);
+        }
+#undef DYCON_NB
+        DYCON_LAUNCH_CHECK();
+        if (want) {
+            norm_sum_dparams_kernel<<<cdiv(C, 256), 256, 0, stream>>>(workspace, Nb, C, dgamma, dbeta);
+            DYCON_LAUNCH_CHECK();
+        }
+        return DYCON_OK;
+    }
     const NormPlan p = norm_plan(V);
     float* ab = workspace + (size_t)Nb * p.chunks * C * 2;
     dim3 grid(p.chunks, Nb);

@@ -268,17 +268,18 @@ class Engine:
             rm, rv = self.buf.get(prefix + ".running_mean"), self.buf.get(prefix + ".running_var")
         else:
             raise ValueError(kind)
+        # z is kept: the ReLU is not invertible, so the backward needs the pre-norm tensor (xhat of the
+        # clamped voxels still enters the group means)
         if kind == "bn" and not training:
             # eval-mode BatchNorm (ISLES teacher, train_DyCON_ISLES22.py:114): running statistics
             stats = torch.stack([rm, torch.rsqrt(rv + 1e-5)], 1).reshape(-1).contiguous()
+            y = ops.norm_apply(z, stats, Nb, V, C, G, gamma, beta, relu, skip, chan_scale=chan_scale)
         else:
             upd = kind == "bn" and training and self.update_bn
-            stats = ops.norm_stats(z, Nb, V, C, G, 1e-5, rm if upd else None, rv if upd else None, 0.1)
+            y, stats = ops.norm_fwd(z, Nb, V, C, G, gamma, beta, relu, skip, chan_scale, 1e-5, rm if upd else None,
+                                    rv if upd else None, 0.1)
             if upd and prefix + ".num_batches_tracked" in self.buf:
                 self.buf[prefix + ".num_batches_tracked"] += 1
-        # z is kept: the ReLU is not invertible, so the backward needs the pre-norm tensor (xhat of the
-        # clamped voxels still enters the group means)
-        y = ops.norm_apply(z, stats, Nb, V, C, G, gamma, beta, relu, skip, chan_scale=chan_scale)
         if self.recording:
             def bwd():
                 gy = self._take(y)

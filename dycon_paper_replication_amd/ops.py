@@ -195,6 +195,18 @@ def norm_stats(x, Nb, V, C, G, eps=1e-5, running_mean=None, running_var=None, mo
     return stats
 
 
+def norm_fwd(x, Nb, V, C, G, gamma=None, beta=None, relu=True, skip=None, chan_scale=None, eps=1e-5, running_mean=None,
+             running_var=None, momentum=0.1):
+    """statistics + apply (one launch on the small levels).  Returns (y, stats)."""
+    y = torch.empty_like(x)
+    stats = torch.empty(Nb * G * 2, dtype=torch.float32, device=x.device)
+    ws = _ws(query("dycon_norm_workspace", Nb, V, C), x)
+    with _Region("norm_fwd", x.numel() * _es(x) * (4 if skip is not None else 3), 6 * x.numel()):
+        call("dycon_norm_fwd", _p(x), _p(y), dt(x), Nb, V, C, G, eps, _p(stats), _p(gamma), _p(beta), int(relu), _p(skip),
+             _p(chan_scale), _p(running_mean), _p(running_var), momentum, _p(ws), ws.numel() * 4, _s())
+    return y, stats
+
+
 def norm_apply(x, stats, Nb, V, C, G, gamma=None, beta=None, relu=True, skip=None, out=None, chan_scale=None):
     if out is None:
         out = torch.empty_like(x)

@@ -113,6 +113,12 @@ size_t dycon_norm_workspace(int Nb, long long V, int C);
 int dycon_norm_stats(const void* x, int dtype, int Nb, long long V, int C, int G, float eps,
                      float* stats, float* running_mean, float* running_var, float momentum,
                      float* workspace, size_t ws_bytes, dycon_stream_t stream);
+/* statistics + apply in one call: ONE launch when V <= 2048 (12^3, 6^3 levels) (each workgroup owns whole groups of one sample),
+ * otherwise dycon_norm_stats followed by dycon_norm_apply.  Same arguments as those two. */
+int dycon_norm_fwd(const void* x, void* y, int dtype, int Nb, long long V, int C, int G, float eps,
+                   float* stats, const float* gamma, const float* beta, int relu, const void* skip,
+                   const float* chan_scale, float* running_mean, float* running_var, float momentum,
+                   float* workspace, size_t ws_bytes, dycon_stream_t stream);
 /* y = act(gamma*(x-mean)*rstd + beta) * chan_scale[n,c] + skip ; gamma/beta/skip/chan_scale may be
  * NULL; y may alias x.  chan_scale (Nb, C) = keep/(1-p) fuses nn.Dropout3d (VNet.py:177,196,226). */
 int dycon_norm_apply(const void* x, void* y, int dtype, int Nb, long long V, int C, int G,
