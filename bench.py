@@ -81,12 +81,19 @@ def main():
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch multi-GPU runs with torch.distributed.run (one process per GPU)")
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+    ndev = torch.cuda.device_count()
+    dev = torch.device("cuda", local % max(ndev, 1))
+    torch.cuda.set_device(dev)
     pg = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.distributed.init_process_group("nccl", device_id=dev)   # "nccl" == RCCL on ROCm
+        # "nccl" == RCCL on ROCm (one rank per GPU over xGMI).  DYCON_DIST_BACKEND=gloo is only for rehearsing the
+        # multi-rank code path on a single-GPU box (ranks then share the device; RCCL refuses duplicate GPUs).
+        backend = os.environ.get("DYCON_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            torch.distributed.init_process_group("nccl", device_id=dev)
+        else:
+            torch.distributed.init_process_group(backend)
         pg = torch.distributed.group.WORLD
 
     from dycon_paper_replication_amd import ops
@@ -145,10 +152,18 @@ def main():
         peak_t = MFMA_PEAK_TFLOPS.get(dom, 157.3) if args.dtype == "bf16" else 157.3
         f_hbm, f_mfma = gbs / HBM_PEAK_GBS, tfl / peak_t
         bound = "hbm" if (r["bytes"] / (HBM_PEAK_GBS * 1e9)) >= (r["flops"] / (peak_t * 1e12)) else "mfma"
+        traffic = None     # HBM bytes per launch from the PMC passes committed under profiles/ (separate rocprofv3 --pmc runs)
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+            traffic = pmc["per_region"][dom]["hbm_bytes_per_launch"]
+        except (OSError, KeyError, ValueError):
+            pass
         roofline = {"kernel": dom, "bound": bound,
                     "achieved": gbs if bound == "hbm" else tfl, "peak": HBM_PEAK_GBS if bound == "hbm" else peak_t,
                     "unit": "GB/s" if bound == "hbm" else "TFLOP/s", "frac": f_hbm if bound == "hbm" else f_mfma,
-                    "traffic": None, "avg_launch_ms": r["ms"] / r["launches"], "launches_per_step": r["launches"] // nprof,
+                    "traffic": traffic, "algorithmic_bytes_per_launch": r["bytes"] / r["launches"],
+                    "algorithmic_flops_per_launch": r["flops"] / r["launches"],
+                    "avg_launch_ms": r["ms"] / r["launches"], "launches_per_step": r["launches"] // nprof,
                     "hbm_frac": f_hbm, "mfma_frac": f_mfma,
                     "per_kernel_ms_per_step": {k: round(v["ms"] / nprof, 4) for k, v in sorted(summ.items(), key=lambda kv: -kv[1]["ms"])}}
 
