@@ -10,7 +10,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdycon_hip.so")
+LIB_PATH = os.environ.get("DYCON_LIB", os.path.join(_HERE, "libdycon_hip.so"))   # DYCON_LIB: diagnostic builds only
 
 F32, BF16 = 0, 1
 CONV_1X1, CONV_K3, CONV_K2S2 = 0, 1, 2

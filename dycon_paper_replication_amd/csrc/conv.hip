@@ -163,24 +163,37 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const T* __restrict__ X,
     const int kl = kc0 * KC + G * kg;          // this lane's position inside the flattened K = taps*Cin
     int t = kl / Cin, c = kl - t * Cin;
     const T* wf = Wf + (((long long)kc0 * NT + nt0) * 64 + lane) * G;
-    for (int kc = kc0; kc < kc1; ++kc) {
-        Vec16<T> a;
-        a.v = decltype(a.v){};
-        if (mvalid && t < Tn) {
-            int zi, yi, xi;
-            if (src_voxel<MODE>(t, zo, yo, xo, Di, Hi, Wi, zi, yi, xi))
-                a = ld16(X + ((((long long)bo * Di + zi) * Hi + yi) * Wi + xi) * Cin + c);
-        }
+    // k-chunks in batches of 4: the A gathers and B fragments of a batch are all requested before its first MFMA
+    const int tstep = KC / Cin, cstep = KC - tstep * Cin;     // per-chunk advance of (tap, channel)
+    constexpr int UB = 2;
+    for (int kcb = kc0; kcb < kc1; kcb += UB) {
+        Vec16<T> a[UB], bq[UB][NTB];
 #pragma unroll
-        for (int j = 0; j < NTB; ++j) {
-            if (nt0 + j < NT) {
-                const Vec16<T> b = ld16(wf + (long long)j * 64 * G);
-                mma(acc[j], a, b);
+        for (int u = 0; u < UB; ++u) {
+            a[u].v = decltype(a[u].v){};
+            if (kcb + u < kc1) {
+                if (mvalid && t < Tn) {
+                    int zi, yi, xi;
+                    if (src_voxel<MODE>(t, zo, yo, xo, Di, Hi, Wi, zi, yi, xi))
+                        a[u] = ld16(X + ((((long long)bo * Di + zi) * Hi + yi) * Wi + xi) * Cin + c);
+                }
+#pragma unroll
+                for (int j = 0; j < NTB; ++j)
+                    if (nt0 + j < NT) bq[u][j] = ld16(wf + (long long)j * 64 * G);
+                wf += (long long)NT * 64 * G;
+                t += tstep;
+                c += cstep;
+                if (c >= Cin) { c -= Cin; ++t; }
             }
         }
-        wf += (long long)NT * 64 * G;
-        c += KC;
-        while (c >= Cin) { c -= Cin; ++t; }
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+            if (kcb + u < kc1) {
+#pragma unroll
+                for (int j = 0; j < NTB; ++j)
+                    if (nt0 + j < NT) mma(acc[j], a[u], bq[u][j]);
+            }
+        }
     }
 
     // epilogue: C/D layout of the 16x16 tile: column = lane&15, row = 4*(lane>>4) + i
@@ -267,9 +280,17 @@ __global__ __launch_bounds__(256) void conv_k3_lds_kernel(const bf16* __restrict
     constexpr int WN = 4 / WM;                 // waves along N
     constexpr int MTW = 16 / WM;               // m-tiles per wave
     constexpr int NTW = NTB / WN;              // n-tiles per wave
-    constexpr int VS = CK == 32 ? 40 : 16;     // LDS voxel stride in elements (80 B / 32 B)
-    constexpr int LDS_ELEMS = CL_NH * VS > CL_NV * (NTB * 16 + 8) ? CL_NH * VS : CL_NV * (NTB * 16 + 8);
-    __shared__ __attribute__((aligned(16))) unsigned short Xh[LDS_ELEMS];
+    // LDS image of the halo tile, laid out so that every ds_read_b128 lane group (16 lanes = 8 x-neighbours of two y-rows,
+    // two channel chunks) hits 16 distinct 16-byte bank slots for every tap (SQ_LDS_BANK_CONFLICT = 0):
+    //   CK = 32: 64 B per voxel, x-row pitch 10 voxels (= 8 slots mod 16), the four 16-B chunks of a voxel rotated by its
+    //            halo x:  chunk c of voxel hx sits at position (c + hx) & 3
+    //   CK = 16: 32 B per voxel, x-row pitch padded to 16 voxels (= 0 slots mod 16), chunks in place
+    constexpr int VS = CK;                      // LDS voxel stride in elements
+    constexpr int RP = CK == 32 ? CL_HX : 16;   // x-row pitch in voxels
+    constexpr int HALO_ELEMS = CL_HZ * CL_HY * RP * VS;
+    constexpr int LDS_ELEMS = HALO_ELEMS > CL_NV * (NTB * 16 + 8) ? HALO_ELEMS : CL_NV * (NTB * 16 + 8);
+    __shared__ __attribute__((aligned(16))) unsigned short Xh[LDS_ELEMS + (CK == 32 ? 9 : 7) * NTB * 64 * 8];
+    unsigned short* Bs = Xh + LDS_ELEMS;       // one group of B fragments: [k-step][n-tile][lane][8]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 15, kg = lane >> 4;
     const int wm = wave / WN, wn = wave % WN;
@@ -279,8 +300,6 @@ __global__ __launch_bounds__(256) void conv_k3_lds_kernel(const bf16* __restrict
     const int tz = tile % tilesZ;
     const int b = tile / tilesZ;
     const int z0 = tz * CL_TZ, y0 = ty * CL_TY, x0 = tx * CL_TX;
-    const int nt0 = blockIdx.y * NTB + wn * NTW;
-
     f32x4 acc[MTW][NTW];
 #pragma unroll
     for (int m = 0; m < MTW; ++m)
@@ -292,65 +311,119 @@ __global__ __launch_bounds__(256) void conv_k3_lds_kernel(const bf16* __restrict
 #pragma unroll
     for (int m = 0; m < MTW; ++m) {
         const int v = (wm * MTW + m) * 16 + r;                 // voxel index inside the tile: (z, y, x) = (v/64, (v/8)%8, v%8)
-        vbase[m] = (((v >> 6) * CL_HY + ((v >> 3) & 7)) * CL_HX + (v & 7)) * VS;
+        vbase[m] = (((v >> 6) * CL_HY + ((v >> 3) & 7)) * RP + (v & 7)) * VS;
     }
     const int nChunks = CIN1 ? 1 : Cin / CK;
     constexpr int NKS = CK == 32 ? 27 : 14;                    // MFMA k-steps (32 wide) per chunk
-    for (int ch = 0; ch < nChunks; ++ch) {
-        __syncthreads();
-        // ---- stage the halo tile of channels [ch*CK, ch*CK + CK)
-        constexpr int PPV = CK / 8;                            // 16-byte pieces per voxel
-        constexpr int NST = (CL_NH * PPV + 255) / 256;         // staging pieces per thread
-        uint4 stg[NST];
-        if (CIN1) {
-            // first layer (one input channel): channel 0 of the 16-wide LDS rows carries x, channels 1..15 are ZERO, so
-            // the packed weights may alias channel 0 for every c (pack with s_c = 0): 0 * w contributes nothing
+    constexpr int GRP = CK == 32 ? 9 : 7;                      // k-steps per B group
+    constexpr int NG = NKS / GRP;                              // groups per chunk (3 or 2)
+    constexpr int PPV = CK / 8;                                // 16-byte pieces per halo voxel
+    constexpr int NST = (CL_NH * PPV + 255) / 256;             // halo pieces per thread
+    constexpr int BPIECES = GRP * NTB * 64;                    // 16-byte pieces of one B group (all n-tiles of the workgroup)
+    constexpr int NSB = (BPIECES + 255) / 256;                 // B pieces per thread
+
+    // Register-staged pipeline (issue early / write late): while the MFMAs of phase p run, the global loads of phase p+1
+    // (next B group, and the next chunk's halo at a chunk boundary) are already in flight in registers; they are written to
+    // LDS after the barrier that retires phase p.  B fragments go through LDS so the four waves fetch them from L2 ONCE.
+    uint4 stgH[NST], stgB[NSB];
+    auto load_halo = [&](int ch) {
 #pragma unroll
-            for (int it = 0; it < NST; ++it) {
-                const int e = threadIdx.x + 256 * it;
-                const int hv = e / PPV, pc = e % PPV;
-                const int hx = hv % CL_HX, hy = (hv / CL_HX) % CL_HY, hz = hv / (CL_HX * CL_HY);
-                const int z = z0 + hz - 1, y = y0 + hy - 1, x = x0 + hx - 1;
-                unsigned v0 = 0;
-                if (pc == 0 && e < CL_NH * PPV && (unsigned)z < (unsigned)D && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W)
-                    v0 = reinterpret_cast<const unsigned short*>(X)[(((long long)b * D + z) * H + y) * W + x];
-                stg[it] = make_uint4(v0, 0, 0, 0);
-            }
-        } else
-#pragma unroll
-        for (int it = 0; it < NST; ++it) {                     // all loads in flight first ...
+        for (int it = 0; it < NST; ++it) {
             const int e = threadIdx.x + 256 * it;
             const int hv = e / PPV, pc = e % PPV;
             const int hx = hv % CL_HX, hy = (hv / CL_HX) % CL_HY, hz = hv / (CL_HX * CL_HY);
             const int z = z0 + hz - 1, y = y0 + hy - 1, x = x0 + hx - 1;
-            stg[it] = make_uint4(0, 0, 0, 0);
-            if (e < CL_NH * PPV && (unsigned)z < (unsigned)D && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W)
-                stg[it] = *reinterpret_cast<const uint4*>(X + ((((long long)b * D + z) * H + y) * W + x) * Cin + ch * CK + 8 * pc);
+            stgH[it] = make_uint4(0, 0, 0, 0);
+            const bool in = e < CL_NH * PPV && (unsigned)z < (unsigned)D && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
+            if (CIN1) {
+                // first layer (one input channel): channel 0 of the 16-wide LDS rows carries x, channels 1..15 are ZERO, so
+                // the packed weights may alias channel 0 for every c (pack with s_c = 0): 0 * w contributes nothing
+                if (in && pc == 0) stgH[it].x = reinterpret_cast<const unsigned short*>(X)[(((long long)b * D + z) * H + y) * W + x];
+            } else if (in) {
+                stgH[it] = *reinterpret_cast<const uint4*>(X + ((((long long)b * D + z) * H + y) * W + x) * Cin + ch * CK + 8 * pc);
+            }
+        }
+    };
+    auto store_halo = [&]() {
+#pragma unroll
+        for (int it = 0; it < NST; ++it) {
+            const int e = threadIdx.x + 256 * it;
+            if (e < CL_NH * PPV) {
+                const int hv = e / PPV, pc = e % PPV;
+                const int hx = hv % CL_HX, hyz = hv / CL_HX;
+                const int pos = CK == 32 ? ((pc + hx) & 3) : pc;
+                *reinterpret_cast<uint4*>(Xh + (hyz * RP + hx) * VS + 8 * pos) = stgH[it];
+            }
+        }
+    };
+    auto load_b = [&](int ch, int g) {
+#pragma unroll
+        for (int it = 0; it < NSB; ++it) {
+            const int e = threadIdx.x + 256 * it;          // piece (u, j, lane)
+            const int ln = e & 63, j = (e >> 6) % NTB, u = e / (64 * NTB);
+            const int ks = g * GRP + u;
+            const int kc = CK == 32 ? ks * nChunks + ch : ks;   // flattened-K chunk (K = tap*Cin + channel, 32 per chunk)
+            stgB[it] = make_uint4(0, 0, 0, 0);
+            if (e < BPIECES)
+                stgB[it] = *reinterpret_cast<const uint4*>(Wf + (((long long)kc * NT + blockIdx.y * NTB + j) * 64 + ln) * 8);
+        }
+    };
+    auto store_b = [&]() {
+#pragma unroll
+        for (int it = 0; it < NSB; ++it) {
+            const int e = threadIdx.x + 256 * it;
+            if (e < BPIECES) *reinterpret_cast<uint4*>(Bs + e * 8) = stgB[it];
+        }
+    };
+    auto tap_off = [&](int ks) {
+        int t, coff;
+        if (CK == 32) { t = ks; coff = 8 * ((kg + (r & 7) + t % 3) & 3); }             // rotated chunk of halo voxel x + dx
+        else { t = 2 * ks + (kg >> 1); coff = 8 * (kg & 1); if (t > 26) t = 26; }   // tap 27 is padding: its packed weights are 0
+        return ((t / 9) * CL_HY * RP + ((t / 3) % 3) * RP + (t % 3)) * VS + coff;
+    };
+
+    load_halo(0);
+    load_b(0, 0);
+    store_halo();
+    store_b();
+    __syncthreads();
+    const int nPhases = nChunks * NG;
+#pragma unroll 1
+    for (int ph = 0; ph < nPhases; ++ph) {
+        const int ch = ph / NG, g = ph - ch * NG;
+        const bool has_next = ph + 1 < nPhases;
+        const bool next_chunk = has_next && g == NG - 1;
+        if (has_next) load_b(next_chunk ? ch + 1 : ch, next_chunk ? 0 : g + 1);
+        if (next_chunk) load_halo(ch + 1);
+        // ---- phase p: GRP k-steps from LDS.  A fragments are read one k-step ahead of their MFMAs.
+        bf16x8 afr[2][MTW];
+        {
+            const int toff = tap_off(g * GRP);
+#pragma unroll
+            for (int m = 0; m < MTW; ++m) afr[0][m] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(Xh + vbase[m] + toff));
         }
 #pragma unroll
-        for (int it = 0; it < NST; ++it) {                     // ... then the LDS writes
-            const int e = threadIdx.x + 256 * it;
-            if (e < CL_NH * PPV) *reinterpret_cast<uint4*>(Xh + (e / PPV) * VS + 8 * (e % PPV)) = stg[it];
-        }
-        __syncthreads();
-#pragma unroll 2
-        for (int ks = 0; ks < NKS; ++ks) {
-            int t, coff;
-            if (CK == 32) { t = ks; coff = 8 * kg; }
-            else { t = 2 * ks + (kg >> 1); coff = 8 * (kg & 1); if (t > 26) t = 26; }   // tap 27 is padding: its packed weights are 0
-            const int toff = ((t / 9) * CL_HY * CL_HX + ((t / 3) % 3) * CL_HX + (t % 3)) * VS + coff;
-            // flattened-K chunk index of this k-step in the packed weights (K = tap*Cin + channel, 32 per chunk)
-            const int kc = CK == 32 ? ks * nChunks + ch : ks;
+        for (int u = 0; u < GRP; ++u) {
             bf16x8 bfr[NTW];
 #pragma unroll
             for (int j = 0; j < NTW; ++j)
-                bfr[j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(Wf + (((long long)kc * NT + nt0 + j) * 64 + lane) * 8));
+                bfr[j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(Bs + ((u * NTB + wn * NTW + j) * 64 + lane) * 8));
+            if (u + 1 < GRP) {
+                const int toff = tap_off(g * GRP + u + 1);
 #pragma unroll
-            for (int m = 0; m < MTW; ++m) {
-                const bf16x8 afr = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(Xh + vbase[m] + toff));
-#pragma unroll
-                for (int j = 0; j < NTW; ++j) acc[m][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr, bfr[j], acc[m][j], 0, 0, 0);
+                for (int m = 0; m < MTW; ++m)
+                    afr[(u + 1) & 1][m] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(Xh + vbase[m] + toff));
             }
+#pragma unroll
+            for (int m = 0; m < MTW; ++m)
+#pragma unroll
+                for (int j = 0; j < NTW; ++j) acc[m][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[u & 1][m], bfr[j], acc[m][j], 0, 0, 0);
+        }
+        if (has_next) {
+            __syncthreads();                 // phase p fully consumed
+            store_b();
+            if (next_chunk) store_halo();
+            __syncthreads();
         }
     }
     // ---- epilogue through LDS: the D fragments hold one channel per lane (2-byte scattered stores would be
