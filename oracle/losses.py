@@ -132,6 +132,57 @@ def fecl(feat, mask, teacher_feat: Optional[torch.Tensor] = None,
     return loss
 
 
+def fecl_rowblocks(feat, mask, teacher_feat, epoch=0, temperature=0.6, gamma=2.0, use_focal=True, rampup_epochs=2000,
+                   lambda_cross=1.0, block=1024):
+    """Memory-light evaluation of the SAME function as ``fecl`` (no gambling branch) for large N: rows are processed in blocks
+    against all N columns, the backward runs block by block.  Returns (loss value, d loss / d feat) as detached tensors.
+    Used to pin the HIP kernel at N = 15 680 (ISLES, feature_scaler 4), where the (N, N) formulation needs ~12 GB/sample.
+    Checked against ``fecl`` itself in tests/test_oracle_golden.py."""
+    B, N, _ = feat.shape
+    m = mask.reshape(B, N)
+    thr = threshold_rampup(epoch, rampup_epochs, 0.3, 0.5)
+    f0 = feat.detach()
+    # pass A (no grad): column max and the global cross-branch count
+    colmax = torch.zeros(B, N, dtype=feat.dtype)
+    cnt = 0.0
+    for b in range(B):
+        for r0 in range(0, N, block):
+            rows = slice(r0, min(N, r0 + block))
+            L = f0[b, rows] @ f0[b].t() / temperature
+            idx = torch.arange(rows.start, rows.stop)
+            L[torch.arange(len(idx)), idx] = 0.0
+            colmax[b] = torch.maximum(colmax[b], L.max(0)[0])
+            if teacher_feat is not None:
+                S = f0[b, rows] @ teacher_feat[b].t()
+                cnt += float(((m[b, rows][:, None] != m[b][None, :]) & (S > thr)).sum())
+    # pass B: loss and gradient block by block
+    leaf = f0.clone().requires_grad_(True)
+    total = 0.0
+    for b in range(B):
+        for r0 in range(0, N, block):
+            rows = slice(r0, min(N, r0 + block))
+            nr = rows.stop - rows.start
+            idx = torch.arange(rows.start, rows.stop)
+            same = (m[b, rows][:, None] == m[b][None, :]).to(feat.dtype)
+            off = torch.ones(nr, N, dtype=feat.dtype)
+            off[torch.arange(nr), idx] = 0.0
+            L = (leaf[b, rows] @ leaf[b].t()) / temperature * off - colmax[b][None, :]
+            E = torch.exp(L)
+            neg = (E * (1 - same)).sum(-1, keepdim=True)
+            P = E / (E + neg + 1e-18)
+            ell = -torch.log(P + 1e-18) * same * off
+            if use_focal:
+                ell = ell * torch.where(same.bool(), (1 - P) ** gamma, torch.ones_like(P))
+            part = (ell.sum(-1) / (same.sum(-1) - 1 + 1e-18)).sum() / (B * N)
+            if teacher_feat is not None and cnt > 0:
+                S = leaf[b, rows] @ teacher_feat[b].t()
+                hard = ((1 - same).bool() & (S > thr)).to(feat.dtype)
+                part = part + lambda_cross * (-torch.log(1 - S + 1e-18) * hard).sum() / (cnt + 1e-18)
+            part.backward()
+            total += float(part.detach())
+    return torch.tensor(total, dtype=feat.dtype), leaf.grad.detach()
+
+
 def embed(features):
     """train_DyCON_BraTS19.py:316-323: (B,C,d,h,w) -> (B,N,C) rows L2-normalised (eps 1e-12)."""
     B, C = features.shape[:2]

@@ -115,3 +115,42 @@ def test_vnet_dropout3d_masks_vs_oracle():
         ref = dict(zip(names, grads))[k]
         got = eng.g[k].cpu()
         assert (got - ref).abs().max() <= 2e-3 * ref.abs().max() + 1e-6, k
+
+
+def test_vnet_isles_geometry_vs_oracle():
+    """BASELINE config 5 geometry: 112x112x80 patches (odd sizes 7x7x5 at the bottleneck, partial tiles everywhere),
+    feature_scaler 4 -> 28x28x20 = 15 680 patch embeddings.  fp32 storage vs the oracle, forward only (B = 1)."""
+    eng, p_all = build("vnet", 3)
+    eng.scale_factor = 4
+    torch.manual_seed(1)
+    x = torch.randn(1, 1, 112, 112, 80)
+    with torch.no_grad():
+        _, lo_ref, fe_ref = ON.vnet_forward(x, p_all, scale_factor=4)
+    logits, feats, _ = eng.forward(x.permute(0, 2, 3, 4, 1).contiguous().to(DEV), record=False)
+    assert tuple(feats.shape) == (1, 28, 28, 20, 256)
+    np.testing.assert_allclose(logits.cpu().permute(0, 4, 1, 2, 3).numpy(), lo_ref.numpy(), rtol=3e-4, atol=3e-4)
+    np.testing.assert_allclose(feats.cpu().permute(0, 4, 1, 2, 3).numpy(), fe_ref.numpy(), rtol=3e-4, atol=3e-4)
+
+
+def test_bf16_step_gradient_tracks_fp32_isles_geometry():
+    """One full DyCON step at 112x112x80 (feature_scaler 4, ISLES variants: multi-class Dice, eval-mode teacher) in bf16 and
+    fp32 storage from the same state: the flat gradient arenas agree in direction and size."""
+    from dycon_paper_replication_amd.engine import DropoutSpec
+    from dycon_paper_replication_amd.synthetic import make_batch
+    from dycon_paper_replication_amd.trainer import DyconTrainer, TrainConfig
+    vol, lab, noise = make_batch(5, 2, (112, 112, 80))
+    grads, losses = {}, {}
+    for dt in (torch.float32, torch.bfloat16):
+        cfg = TrainConfig(model="vnet", labeled_bs=1, batch_size=2, dtype=dt, feature_scaler=4, dice_variant="multiclass",
+                          teacher_mode="eval", poly_lr=True, seed=11)
+        tr = DyconTrainer(cfg, DEV)
+        off = DropoutSpec("off")
+        out = tr.step(vol.to(DEV), lab.to(DEV), noise=noise.to(DEV), s_drop=off, t_drop=off)
+        assert not out["skipped"]
+        grads[dt] = tr.flat_g[: tr.n_sgd].clone()
+        losses[dt] = [float(out[k]) for k in ("loss", "ce", "dice", "cons", "fecl", "uncl")]
+    a, b = grads[torch.bfloat16], grads[torch.float32]
+    cos = float((a * b).sum() / (a.norm() * b.norm()))
+    ratio = float(a.norm() / b.norm())
+    assert cos > 0.98 and 0.9 < ratio < 1.1, (cos, ratio)
+    np.testing.assert_allclose(losses[torch.bfloat16], losses[torch.float32], rtol=3e-2, atol=3e-3)

@@ -377,3 +377,25 @@ def test_optimizer():
     f2 = torch.zeros(1, dtype=torch.int32, device=DEV)
     ops.nonfinite_flag(torch.tensor([float("nan")], device=DEV), f2)
     assert int(f2) == 1
+
+
+def test_fecl_isles_size_vs_rowblock_oracle():
+    """N = 15 680 patches (ISLES, feature_scaler 4): far beyond what the reference can materialise (12 N x N fp32 tensors =
+    11.8 GB per sample).  The HIP kernel (fp32 storage) against the row-block oracle, loss and gradient; bf16 storage on the loss."""
+    torch.manual_seed(4)
+    B, N, Dm = 1, 15680, 256
+    f = F.normalize(torch.randn(B, N, Dm), dim=-1)
+    t = F.normalize(f + 0.05 * torch.randn(B, N, Dm), dim=-1)
+    mask = (torch.rand(B, N) > 0.9).float()
+    epoch = 600
+    thr = OL.threshold_rampup(epoch, 1500, 0.3, 0.5)
+    ref, gref = OL.fecl_rowblocks(f, mask.view(B, 1, N), t, epoch, 0.6, 2.0, True, 1500, 1.0, block=1024)
+    args = lambda ff, tt: (ff, tt, mask.to(DEV), None, 0.6, 2.0, True, thr, 1.0)  # noqa: E731
+    l32, st = ops.fecl_fwd(*args(f.to(DEV), t.to(DEV)))
+    close(l32[0], ref, 1e-4, 1e-6)
+    g32 = ops.fecl_bwd(*args(f.to(DEV), t.to(DEV)), st, torch.ones(1, device=DEV))
+    err = float((g32.cpu() - gref).abs().max())
+    assert err <= 1e-3 * float(gref.abs().max()) + 1e-9, err
+    l16, _ = ops.fecl_fwd(*args(f.to(DEV).bfloat16(), t.to(DEV).bfloat16()))
+    ref16, _ = OL.fecl_rowblocks(f.bfloat16().float(), mask.view(B, 1, N), t.bfloat16().float(), epoch, 0.6, 2.0, True, 1500, 1.0, block=2048)
+    close(l16[0], ref16, 5e-4, 1e-6)

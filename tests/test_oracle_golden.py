@@ -58,6 +58,19 @@ def test_fecl(tag):
         close(l64, g[f"loss64_{i}"], 1e-11, 0)
 
 
+def test_fecl_rowblocks_equals_fecl():
+    """the memory-light evaluation used at N = 15 680 is the same function as the pinned oracle"""
+    g = load_golden("fecl_mid")
+    f, t, m = T(g["feat"]), T(g["teacher"]), T(g["mask"])
+    for epoch, focal in ((0, True), (900, False), (3000, True)):
+        fr = f.clone().requires_grad_(True)
+        ref = OL.fecl(fr, m, t, None, epoch, 0.6, 2.0, focal, 1500, 1.0)
+        (gr,) = torch.autograd.grad(ref, fr)
+        val, grad = OL.fecl_rowblocks(f, m, t, epoch, 0.6, 2.0, focal, 1500, 1.0, block=50)
+        close(val, ref.detach(), 1e-5, 1e-7)
+        close(grad, gr, 1e-4, 1e-8)
+
+
 def test_voxel_losses():
     g = load_golden("voxel_losses")
     a, b, lab = T(g["a"]), T(g["b"]), T(g["label"])
