@@ -362,7 +362,9 @@ __global__ __launch_bounds__(256) void conv_k3_lds_kernel(const bf16* __restrict
             const int e = threadIdx.x + 256 * it;          // piece (u, j, lane)
             const int ln = e & 63, j = (e >> 6) % NTB, u = e / (64 * NTB);
             const int ks = g * GRP + u;
-            const int kc = CK == 32 ? ks * nChunks + ch : ks;   // flattened-K chunk (K = tap*Cin + channel, 32 per chunk)
+            // CK = 32: flattened K = tap*Cin + channel in 32-chunks.  CK = 16: weights packed chunk-major (each 16-channel
+            // chunk as its own 27-tap x 16 problem, 14 k-steps), so 48-channel inputs (U-Net decoder) run here too
+            const int kc = CK == 32 ? ks * nChunks + ch : ch * NKS + ks;
             stgB[it] = make_uint4(0, 0, 0, 0);
             if (e < BPIECES)
                 stgB[it] = *reinterpret_cast<const uint4*>(Wf + (((long long)kc * NT + blockIdx.y * NTB + j) * 64 + ln) * 8);
@@ -1201,11 +1203,11 @@ extern "C" int dycon_conv_gemm(const void* x, const void* wfrag, const float* bi
     DYCON_REQUIRE(scatter || N == Cout, "conv_gemm: N must equal Cout without scatter");
     DYCON_REQUIRE(mode != DYCON_CONV_K2S2 || (Di % 2 == 0 && Hi % 2 == 0 && Wi % 2 == 0), "conv_gemm: k2s2 needs even dims");
     // large spatial levels, bf16: LDS-halo kernel
-    if (dtype == DYCON_BF16 && mode == DYCON_CONV_K3 && !scatter && (Cin == 1 || Cin == 16 || Cin % 32 == 0) &&
-        (Cout == 16 || Cout == 32 || Cout % 64 == 0) && (long long)Di * Hi * Wi >= 13824) {
+    if (dtype == DYCON_BF16 && mode == DYCON_CONV_K3 && !scatter && (Cin == 1 || Cin == 16 || Cin == 48 || Cin % 32 == 0) &&
+        (Cout == 16 || Cout == 32 || Cout % 64 == 0 || Cout % 48 == 0) && (long long)Di * Hi * Wi >= 13824) {
         const int tz = cdiv(Di, CL_TZ), ty = cdiv(Hi, CL_TY), tx = cdiv(Wi, CL_TX);
         const int NT = Cout / 16;
-        const int ntb = Cout >= 64 ? 4 : NT;
+        const int ntb = Cout % 64 == 0 ? 4 : (Cout % 48 == 0 ? 3 : NT);
         dim3 grid(B * tz * ty * tx, NT / ntb);
 #define DYCON_CL(CKV, NTBV, WMV) \
     conv_k3_lds_kernel<CKV, NTBV, WMV><<<grid, 256, 0, stream>>>((const bf16*)x, (const bf16*)wfrag, bias, (bf16*)y, B, Di, Hi, Wi, Cin, Cout, NT, tz, ty, tx, accumulate)
@@ -1213,8 +1215,11 @@ extern "C" int dycon_conv_gemm(const void* x, const void* wfrag, const float* bi
             if (ntb == 1) conv_k3_lds_kernel<16, 1, 4, true><<<grid, 256, 0, stream>>>((const bf16*)x, (const bf16*)wfrag, bias, (bf16*)y, B, Di, Hi, Wi, 1, Cout, NT, tz, ty, tx, accumulate);
             else if (ntb == 2) conv_k3_lds_kernel<16, 2, 4, true><<<grid, 256, 0, stream>>>((const bf16*)x, (const bf16*)wfrag, bias, (bf16*)y, B, Di, Hi, Wi, 1, Cout, NT, tz, ty, tx, accumulate);
             else conv_k3_lds_kernel<16, 4, 2, true><<<grid, 256, 0, stream>>>((const bf16*)x, (const bf16*)wfrag, bias, (bf16*)y, B, Di, Hi, Wi, 1, Cout, NT, tz, ty, tx, accumulate);
-        } else if (Cin == 16) { if (ntb == 1) DYCON_CL(16, 1, 4); else if (ntb == 2) DYCON_CL(16, 2, 4); else DYCON_CL(16, 4, 2); }
-        else { if (ntb == 1) DYCON_CL(32, 1, 4); else if (ntb == 2) DYCON_CL(32, 2, 4); else DYCON_CL(32, 4, 2); }
+        } else if (Cin == 16 || Cin == 48) {
+            if (ntb == 1) DYCON_CL(16, 1, 4); else if (ntb == 2) DYCON_CL(16, 2, 4); else if (ntb == 3) DYCON_CL(16, 3, 4); else DYCON_CL(16, 4, 2);
+        } else {
+            if (ntb == 1) DYCON_CL(32, 1, 4); else if (ntb == 2) DYCON_CL(32, 2, 4); else if (ntb == 3) DYCON_CL(32, 3, 4); else DYCON_CL(32, 4, 2);
+        }
 #undef DYCON_CL
         DYCON_LAUNCH_CHECK();
         return DYCON_OK;

@@ -26,48 +26,61 @@ __device__ __forceinline__ float u01(uint32_t x) { return ((float)(x >> 8) + 0.5
 // MaxPool3d(2): first maximum in (dz,dy,dx) scan order wins (ATen CPU/CUDA tie rule; matters because
 // whole windows are 0 after ReLU)
 // ------------------------------------------------------------------------------------------------
+// one thread = one output voxel x VN channels (16-byte loads/stores)
 template <typename T>
 __global__ void maxpool2_fwd_kernel(const T* __restrict__ X, T* __restrict__ Y, uint8_t* __restrict__ idx, int B, int D, int H,
                                     int W, int C, long long total) {
-    const int Do = D / 2, Ho = H / 2, Wo = W / 2;
+    constexpr int VN = Vec16<T>::N;
+    const int Do = D / 2, Ho = H / 2, Wo = W / 2, CG = C / VN;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-        const int c = (int)(i % C);
-        long long q = i / C;
+        const int cg = (int)(i % CG);
+        long long q = i / CG;
         const int x = (int)(q % Wo); q /= Wo;
         const int y = (int)(q % Ho); q /= Ho;
         const int z = (int)(q % Do);
         const int b = (int)(q / Do);
-        float best = 0.f;
-        int bi = 0;
+        float best[VN];
+        int bi[VN];
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
             const long long v = (((long long)b * D + 2 * z + (t >> 2)) * H + 2 * y + ((t >> 1) & 1)) * W + 2 * x + (t & 1);
-            const float f = ldf(X + v * C + c);
-            if (t == 0 || f > best || (f != f && best == best)) { best = f; bi = t; }
+            const Vec16<T> f = ld16(X + v * C + cg * VN);
+#pragma unroll
+            for (int k = 0; k < VN; ++k) {
+                const float fv = f.get(k);
+                if (t == 0 || fv > best[k] || (fv != fv && best[k] == best[k])) { best[k] = fv; bi[k] = t; }
+            }
         }
-        stf(Y + i, best);
-        idx[i] = (uint8_t)bi;
+        const long long o = ((((long long)b * Do + z) * Ho + y) * Wo + x) * C + cg * VN;
+        Vec16<T> out;
+#pragma unroll
+        for (int k = 0; k < VN; ++k) { out.set(k, best[k]); idx[o + k] = (uint8_t)bi[k]; }
+        st16(Y + o, out);
     }
 }
 
 template <typename T>
 __global__ void maxpool2_bwd_kernel(const T* __restrict__ GY, const uint8_t* __restrict__ idx, T* __restrict__ GX, int B, int D,
                                     int H, int W, int C, long long total) {
-    const int Do = D / 2, Ho = H / 2, Wo = W / 2;
+    constexpr int VN = Vec16<T>::N;
+    const int Do = D / 2, Ho = H / 2, Wo = W / 2, CG = C / VN;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-        const int c = (int)(i % C);
-        long long q = i / C;
+        const int cg = (int)(i % CG);
+        long long q = i / CG;
         const int x = (int)(q % W); q /= W;
         const int y = (int)(q % H); q /= H;
         const int z = (int)(q % D);
         const int b = (int)(q / D);
-        float g = 0.f;
+        Vec16<T> g;
+        g.v = decltype(g.v){};
         if ((z >> 1) < Do && (y >> 1) < Ho && (x >> 1) < Wo) {
-            const long long o = ((((long long)b * Do + (z >> 1)) * Ho + (y >> 1)) * Wo + (x >> 1)) * C + c;
+            const long long o = ((((long long)b * Do + (z >> 1)) * Ho + (y >> 1)) * Wo + (x >> 1)) * C + cg * VN;
             const int t = ((z & 1) << 2) | ((y & 1) << 1) | (x & 1);
-            if (idx[o] == t) g = ldf(GY + o);
+            const Vec16<T> gy = ld16(GY + o);
+#pragma unroll
+            for (int k = 0; k < VN; ++k) g.set(k, idx[o + k] == t ? gy.get(k) : 0.f);
         }
-        stf(GX + i, g);
+        st16(GX + ((((long long)b * D + z) * H + y) * W + x) * C + cg * VN, g);
     }
 }
 
@@ -90,12 +103,15 @@ __device__ __forceinline__ void tri_src(int o, int in, int out, int align, int& 
     lam = fminf(fmaxf(src - (float)i0, 0.f), 1.f);
 }
 
+// one thread = one output voxel x VN channels: coordinates once, 8 x 16-byte taps
 template <typename T>
 __global__ void trilinear_fwd_kernel(const T* __restrict__ X, T* __restrict__ Y, int B, int Di, int Hi, int Wi, int Do, int Ho,
                                      int Wo, int C, int ldy, int coff, int align, long long total) {
+    constexpr int VN = Vec16<T>::N;
+    const int CG = C / VN;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-        const int c = (int)(i % C);
-        long long q = i / C;
+        const int cg = (int)(i % CG);
+        long long q = i / CG;
         const int x = (int)(q % Wo); q /= Wo;
         const int y = (int)(q % Ho); q /= Ho;
         const int z = (int)(q % Do);
@@ -105,12 +121,18 @@ __global__ void trilinear_fwd_kernel(const T* __restrict__ X, T* __restrict__ Y,
         tri_src(z, Di, Do, align, z0, z1, lz);
         tri_src(y, Hi, Ho, align, y0, y1, ly);
         tri_src(x, Wi, Wo, align, x0, x1, lx);
-        auto at = [&](int zz, int yy, int xx) { return ldf(X + ((((long long)b * Di + zz) * Hi + yy) * Wi + xx) * C + c); };
+        auto at = [&](int zz, int yy, int xx) { return ld16(X + ((((long long)b * Di + zz) * Hi + yy) * Wi + xx) * C + cg * VN); };
+        const Vec16<T> a000 = at(z0, y0, x0), a001 = at(z0, y0, x1), a010 = at(z0, y1, x0), a011 = at(z0, y1, x1);
+        const Vec16<T> a100 = at(z1, y0, x0), a101 = at(z1, y0, x1), a110 = at(z1, y1, x0), a111 = at(z1, y1, x1);
         const float w0z = 1.f - lz, w0y = 1.f - ly, w0x = 1.f - lx;
-        // same association order as ATen's upsample_trilinear3d
-        const float v = w0z * (w0y * (w0x * at(z0, y0, x0) + lx * at(z0, y0, x1)) + ly * (w0x * at(z0, y1, x0) + lx * at(z0, y1, x1))) +
-                        lz * (w0y * (w0x * at(z1, y0, x0) + lx * at(z1, y0, x1)) + ly * (w0x * at(z1, y1, x0) + lx * at(z1, y1, x1)));
-        stf(Y + ((((long long)b * Do + z) * Ho + y) * Wo + x) * ldy + coff + c, v);
+        Vec16<T> o;
+#pragma unroll
+        for (int k = 0; k < VN; ++k) {   // same association order as ATen's upsample_trilinear3d
+            const float v = w0z * (w0y * (w0x * a000.get(k) + lx * a001.get(k)) + ly * (w0x * a010.get(k) + lx * a011.get(k))) +
+                            lz * (w0y * (w0x * a100.get(k) + lx * a101.get(k)) + ly * (w0x * a110.get(k) + lx * a111.get(k)));
+            o.set(k, v);
+        }
+        st16(Y + ((((long long)b * Do + z) * Ho + y) * Wo + x) * ldy + coff + cg * VN, o);
     }
 }
 
@@ -130,13 +152,17 @@ __device__ __forceinline__ void tri_range(int i, int in, int out, int align, int
     if (hi > out - 1) hi = out - 1;
 }
 
-// gather form of the adjoint: deterministic, no atomics
+// gather form of the adjoint: deterministic, no atomics.  One thread = one input voxel x VN channels; the per-axis weights of the
+// (few) contributing outputs are evaluated once per axis.
 template <typename T>
 __global__ void trilinear_bwd_kernel(const T* __restrict__ GY, T* __restrict__ GX, int B, int Di, int Hi, int Wi, int Do, int Ho,
                                      int Wo, int C, int ldy, int coff, int align, long long total) {
+    constexpr int VN = Vec16<T>::N;
+    constexpr int MAXO = 12;                       // contributing outputs per axis (scale <= 4)
+    const int CG = C / VN;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-        const int c = (int)(i % C);
-        long long q = i / C;
+        const int cg = (int)(i % CG);
+        long long q = i / CG;
         const int x = (int)(q % Wi); q /= Wi;
         const int y = (int)(q % Hi); q /= Hi;
         const int z = (int)(q % Di);
@@ -145,22 +171,30 @@ __global__ void trilinear_bwd_kernel(const T* __restrict__ GY, T* __restrict__ G
         tri_range(z, Di, Do, align, zl, zh);
         tri_range(y, Hi, Ho, align, yl, yh);
         tri_range(x, Wi, Wo, align, xl, xh);
-        float acc = 0.f;
+        float acc[VN];
+#pragma unroll
+        for (int k = 0; k < VN; ++k) acc[k] = 0.f;
         for (int oz = zl; oz <= zh; ++oz) {
             const float wz = tri_w(oz, z, Di, Do, align);
             if (wz == 0.f) continue;
             for (int oy = yl; oy <= yh; ++oy) {
-                const float wy = tri_w(oy, y, Hi, Ho, align);
-                if (wy == 0.f) continue;
+                const float wzy = wz * tri_w(oy, y, Hi, Ho, align);
+                if (wzy == 0.f) continue;
                 for (int ox = xl; ox <= xh; ++ox) {
-                    const float wx = tri_w(ox, x, Wi, Wo, align);
-                    if (wx == 0.f) continue;
-                    acc += wz * wy * wx * ldf(GY + ((((long long)b * Do + oz) * Ho + oy) * Wo + ox) * ldy + coff + c);
+                    const float w = wzy * tri_w(ox, x, Wi, Wo, align);
+                    if (w == 0.f) continue;
+                    const Vec16<T> g = ld16(GY + ((((long long)b * Do + oz) * Ho + oy) * Wo + ox) * ldy + coff + cg * VN);
+#pragma unroll
+                    for (int k = 0; k < VN; ++k) acc[k] += w * g.get(k);
                 }
             }
         }
-        stf(GX + i, acc);
+        Vec16<T> o;
+#pragma unroll
+        for (int k = 0; k < VN; ++k) o.set(k, acc[k]);
+        st16(GX + i * VN, o);
     }
+    (void)MAXO;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -169,6 +203,17 @@ __global__ void trilinear_bwd_kernel(const T* __restrict__ GY, T* __restrict__ G
 template <typename T>
 __global__ void copy_channels_kernel(const T* __restrict__ S, int lds, int soff, T* __restrict__ Dst, int ldd, int doff,
                                      long long rows, int C) {
+    constexpr int VN = Vec16<T>::N;
+    if (C % VN == 0 && lds % VN == 0 && ldd % VN == 0 && soff % VN == 0 && doff % VN == 0) {
+        const int CG = C / VN;
+        const long long total = rows * CG;
+        for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+            const long long r = i / CG;
+            const int c = (int)(i % CG) * VN;
+            st16(Dst + r * ldd + doff + c, ld16(S + r * lds + soff + c));
+        }
+        return;
+    }
     const long long total = rows * C;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         const long long r = i / C;
@@ -276,7 +321,8 @@ static inline int sgrid(long long n) {
 extern "C" int dycon_maxpool2_fwd(const void* x, void* y, uint8_t* idx, int dtype, int B, int D, int H, int W, int C,
                                   dycon_stream_t stream) {
     DYCON_REQUIRE(x && y && idx && B > 0 && D > 1 && H > 1 && W > 1 && C > 0, "maxpool2_fwd: bad arguments");
-    const long long total = (long long)B * (D / 2) * (H / 2) * (W / 2) * C;
+    DYCON_REQUIRE(C % (dtype == DYCON_BF16 ? 8 : 4) == 0, "maxpool2_fwd: C=%d must be a multiple of the 16-byte vector width", C);
+    const long long total = (long long)B * (D / 2) * (H / 2) * (W / 2) * (C / (dtype == DYCON_BF16 ? 8 : 4));
     DYCON_DISPATCH(dtype, { maxpool2_fwd_kernel<T><<<sgrid(total), 256, 0, stream>>>((const T*)x, (T*)y, idx, B, D, H, W, C, total); });
     DYCON_LAUNCH_CHECK();
     return DYCON_OK;
@@ -285,7 +331,8 @@ extern "C" int dycon_maxpool2_fwd(const void* x, void* y, uint8_t* idx, int dtyp
 extern "C" int dycon_maxpool2_bwd(const void* gy, const uint8_t* idx, void* gx, int dtype, int B, int D, int H, int W, int C,
                                   dycon_stream_t stream) {
     DYCON_REQUIRE(gy && gx && idx && B > 0 && D > 1 && H > 1 && W > 1 && C > 0, "maxpool2_bwd: bad arguments");
-    const long long total = (long long)B * D * H * W * C;
+    DYCON_REQUIRE(C % (dtype == DYCON_BF16 ? 8 : 4) == 0, "maxpool2_bwd: C=%d must be a multiple of the 16-byte vector width", C);
+    const long long total = (long long)B * D * H * W * (C / (dtype == DYCON_BF16 ? 8 : 4));
     DYCON_DISPATCH(dtype, { maxpool2_bwd_kernel<T><<<sgrid(total), 256, 0, stream>>>((const T*)gy, idx, (T*)gx, B, D, H, W, C, total); });
     DYCON_LAUNCH_CHECK();
     return DYCON_OK;
@@ -295,7 +342,9 @@ extern "C" int dycon_trilinear_fwd(const void* x, void* y, int dtype, int B, int
                                    int C, int ldy, int coff, int align_corners, dycon_stream_t stream) {
     DYCON_REQUIRE(x && y && B > 0 && Di > 0 && Hi > 0 && Wi > 0 && Do > 0 && Ho > 0 && Wo > 0 && C > 0, "trilinear_fwd: bad shape");
     DYCON_REQUIRE(coff >= 0 && coff + C <= ldy, "trilinear_fwd: channel window [%d,%d) outside ld %d", coff, coff + C, ldy);
-    const long long total = (long long)B * Do * Ho * Wo * C;
+    const int vn_ = dtype == DYCON_BF16 ? 8 : 4;
+    DYCON_REQUIRE(C % vn_ == 0 && ldy % vn_ == 0 && coff % vn_ == 0, "trilinear_fwd: C, ldy, coff must be multiples of %d", vn_);
+    const long long total = (long long)B * Do * Ho * Wo * (C / vn_);
     DYCON_DISPATCH(dtype, {
         trilinear_fwd_kernel<T><<<sgrid(total), 256, 0, stream>>>((const T*)x, (T*)y, B, Di, Hi, Wi, Do, Ho, Wo, C, ldy, coff, align_corners, total);
     });
@@ -307,7 +356,9 @@ extern "C" int dycon_trilinear_bwd(const void* gy, void* gx, int dtype, int B, i
                                    int C, int ldy, int coff, int align_corners, dycon_stream_t stream) {
     DYCON_REQUIRE(gy && gx && B > 0 && Di > 0 && Hi > 0 && Wi > 0 && Do > 0 && Ho > 0 && Wo > 0 && C > 0, "trilinear_bwd: bad shape");
     DYCON_REQUIRE(coff >= 0 && coff + C <= ldy, "trilinear_bwd: channel window outside ld");
-    const long long total = (long long)B * Di * Hi * Wi * C;
+    const int vn_ = dtype == DYCON_BF16 ? 8 : 4;
+    DYCON_REQUIRE(C % vn_ == 0 && ldy % vn_ == 0 && coff % vn_ == 0, "trilinear_bwd: C, ldy, coff must be multiples of %d", vn_);
+    const long long total = (long long)B * Di * Hi * Wi * (C / vn_);
     DYCON_DISPATCH(dtype, {
         trilinear_bwd_kernel<T><<<sgrid(total), 256, 0, stream>>>((const T*)gy, (T*)gx, B, Di, Hi, Wi, Do, Ho, Wo, C, ldy, coff, align_corners, total);
     });

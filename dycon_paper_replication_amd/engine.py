@@ -169,6 +169,24 @@ class Engine:
         self._packed[key] = (self.gen, buf)
         return buf
 
+    def _pk_chunked16(self, key, w, nchunks, N, s_t, s_c, s_n0, flip=False):
+        """bf16 k=3 weights for the LDS-halo kernel with 48 input channels: chunk-major, one (T=27, Cin=16) pack per 16-channel
+        chunk, back to back in one buffer (include/dycon_hip.h, dycon_conv_gemm)."""
+        hit = self._packed.get(key)
+        if hit is not None and hit[0] == self.gen:
+            return hit[1]
+        per = ops.query("dycon_bfrag_bytes", ops.BF16, 27, 16, N) // 2
+        buf = hit[1] if hit is not None else torch.empty(per * nchunks, dtype=torch.bfloat16, device=w.device)
+        wflat = w.reshape(-1)
+        for ch in range(nchunks):
+            src, dst = wflat[ch * 16 * s_c:], buf[ch * per:(ch + 1) * per]
+            ops.pack_bfrag(src, self.dtype, 27, 16, N, N, s_t, s_c, 0, s_n0, flip, out=dst)
+            if hit is None:
+                self._jobs.append(((key, ch), ops.pack_job(src, dst, 0, 27, 16, N, N, s_t, s_c, 0, s_n0, flip)))
+                self._jobs_dev = None
+        self._packed[key] = (self.gen, buf)
+        return buf
+
     def repack(self):
         """Refresh every registered packed operand in one launch (call after the parameters changed)."""
         if not self._jobs or self._packed_gen == self.gen:
@@ -179,6 +197,7 @@ class Engine:
         biggest = max(j[6] for _, j in self._jobs)                    # output elements of the largest job
         ops.pack_batch(self._jobs_dev, len(self._jobs), max(1, min(512, (biggest + 2047) // 2048)))
         for key, _ in self._jobs:
+            key = key[0] if isinstance(key[0], tuple) else key        # chunked packs register one job per chunk
             self._packed[key] = (self.gen, self._packed[key][1])
         self._packed_gen = self.gen
 
@@ -216,6 +235,9 @@ class Engine:
         elif kind == "deconv":
             wf = self._pk((name, "f"), "frag", w, 1, Cin, 8 * Cout, Cout, 0, Cout * 8, 1, 8)
             y = ops.conv_gemm(x, wf, b, CONV_1X1, 8 * Cout, Cout, scatter=True)
+        elif kind == "k3" and Cin == 48 and ops.conv_uses_lds(x, Cin, Cout):
+            wf = self._pk_chunked16((name, "f48"), w, 3, Cout, 1, 27, Cin * 27)
+            y = ops.conv_gemm(x, wf, b, mode, Cout, Cout)
         else:
             wf = self._pk((name, "f"), "frag", w, T, Cin, Cout, Cout, 1, T, 0, Cin * T)
             y = ops.conv_gemm(x, wf, b, mode, Cout, Cout)
@@ -236,7 +258,10 @@ class Engine:
                     wd = self._pk((name, "tcn_d"), "tcn", w, 1, Cout, Cin, Cin, 0, Cin, 0, 1)
                     gx = ops.conv_direct(gy, wd, None, CONV_1X1, Cin, x.dtype, out=cur, accumulate=cur is not None)
                 elif kind == "k3":     # conv with flipped taps and transposed channels
-                    wd = self._pk((name, "d"), "frag", w, 27, Cout, Cin, Cin, 1, Cin * 27, 0, 27, flip=True)
+                    if Cout == 48 and ops.conv_uses_lds(gy, Cout, Cin):
+                        wd = self._pk_chunked16((name, "d48"), w, 3, Cin, 1, Cin * 27, 27, flip=True)
+                    else:
+                        wd = self._pk((name, "d"), "frag", w, 27, Cout, Cin, Cin, 1, Cin * 27, 0, 27, flip=True)
                     gx = ops.conv_gemm(gy, wd, None, CONV_K3, Cin, Cin, out=cur, accumulate=cur is not None)
                 elif kind == "k2s2":   # scatter: gx[2m+t, ci] = sum_co gy[m,co] W[co][ci][t]
                     wd = self._pk((name, "d"), "frag", w, 1, Cout, 8 * Cin, Cin, 0, Cin * 8, 1, 8)

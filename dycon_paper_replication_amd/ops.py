@@ -119,6 +119,13 @@ def pack_batch(jobs_dev, njobs, blocks_per_job=8):
     call("dycon_pack_batch", _p(jobs_dev), njobs, blocks_per_job, _s())
 
 
+def conv_uses_lds(x, Cin, Cout):
+    """True when dycon_conv_gemm routes a k=3 conv of this shape to the LDS-halo kernel (bf16, >= 24^3 voxels)."""
+    _, D, H, W, _ = x.shape
+    return (x.dtype == torch.bfloat16 and (Cin in (1, 16, 48) or Cin % 32 == 0)
+            and (Cout in (16, 32) or Cout % 64 == 0 or Cout % 48 == 0) and D * H * W >= 13824)
+
+
 # ------------------------------------------------------------------ conv family
 def conv_gemm(x, wfrag, bias, mode, N, Cout, scatter=False, out=None, accumulate=False):
     B, D, H, W, Cin = x.shape
@@ -135,8 +142,7 @@ def conv_gemm(x, wfrag, bias, mode, N, Cout, scatter=False, out=None, accumulate
     rows = out.numel() // Cout if not scatter else x.numel() // Cin
     nws = query("dycon_conv_gemm_workspace", dt(x), mode, int(scatter), B, D, H, W, Cin, N)
     ws = _ws(nws, x) if nws else None
-    lds_path = (x.dtype == torch.bfloat16 and mode == CONV_K3 and not scatter and (Cin in (1, 16) or Cin % 32 == 0)
-                and (Cout in (16, 32) or Cout % 64 == 0) and D * H * W >= 13824)
+    lds_path = mode == CONV_K3 and not scatter and conv_uses_lds(x, Cin, Cout)
     rname = "conv_k3_lds" if lds_path else ("conv_gemm_splitk" if nws else "conv_gemm")
     with _Region(rname, (x.numel() + out.numel() * (2 if accumulate else 1)) * _es(x) + taps * Cin * N * _es(x),
                  2 * rows * taps * Cin * N):

@@ -66,6 +66,8 @@ CONV_CASES = [
     ("k3", 1, 16, (24, 24, 24)), ("k3", 16, 16, (24, 28, 22)), ("k3", 16, 32, (24, 24, 24)), ("k3", 32, 16, (24, 24, 24)),
     ("k3", 32, 32, (26, 24, 24)), ("k3", 64, 64, (24, 24, 24)), ("k3", 16, 64, (24, 24, 24)), ("k3", 64, 128, (24, 24, 24)),
     ("k3", 32, 1 * 16, (20, 28, 25)),
+    # U-Net decoder widths on the LDS kernel: 48 input channels (chunk-major packing), 48 / 96 output channels (3 n-tiles)
+    ("k3", 48, 16, (24, 24, 24)), ("k3", 96, 32, (24, 24, 24)), ("k3", 16, 48, (24, 24, 24)), ("k3", 32, 96, (24, 24, 24)),
 ]
 
 
@@ -196,19 +198,27 @@ def test_golden_pool_trilinear():
     close(nc(y), g["maxpool.y"], 0, 0)
     gx = ops.maxpool2_bwd(nd(T(g["maxpool.r"])), idx, nd(x).shape)
     close(nc(gx), g["maxpool.gx"], 0, 0)
-    x = T(g["tri.x"])
-    xd = nd(x)
+    x = T(g["tri.x"])                                     # (1, 3, 3, 5, 4): pad to 4 channels (16-byte channel groups)
+    pad = lambda t: torch.cat([t, torch.zeros_like(t[:, :1])], 1)  # noqa: E731
+    xd = nd(pad(x))
     for tag, scale, align in (("up2", 2, False), ("head2", 2, True), ("head4", 4, True)):
         out = tuple(s * scale for s in x.shape[2:])
         y = ops.trilinear_fwd(xd, out, align)
-        close(nc(y), g[f"tri_{tag}.y"], 1e-5, 1e-6, tag)
-        gx = ops.trilinear_bwd(nd(T(g[f"tri_{tag}.r"])), xd.shape, align)
-        close(nc(gx), g[f"tri_{tag}.gx"], 1e-4, 1e-5, tag + " bwd")
+        close(nc(y)[:, :3], g[f"tri_{tag}.y"], 1e-5, 1e-6, tag)
+        assert float(nc(y)[:, 3].abs().max()) == 0
+        gx = ops.trilinear_bwd(nd(pad(T(g[f"tri_{tag}.r"]))), xd.shape, align)
+        close(nc(gx)[:, :3], g[f"tri_{tag}.gx"], 1e-4, 1e-5, tag + " bwd")
     # channel-window variant (concat without a copy)
-    cat = torch.zeros((1, 6, 10, 8, 7), device=DEV)
-    ops.trilinear_fwd(xd, (6, 10, 8), False, out=cat, coff=2)
-    close(nc(cat[..., 2:5].contiguous()), g["tri_up2.y"], 1e-5, 1e-6)
-    assert float(cat[..., :2].abs().max()) == 0 and float(cat[..., 5:].abs().max()) == 0
+    cat = torch.zeros((1, 6, 10, 8, 12), device=DEV)
+    ops.trilinear_fwd(xd, (6, 10, 8), False, out=cat, coff=4)
+    close(nc(cat[..., 4:7].contiguous()), g["tri_up2.y"], 1e-5, 1e-6)
+    assert float(cat[..., :4].abs().max()) == 0 and float(cat[..., 7:].abs().max()) == 0
+    gwin = torch.zeros((1, 6, 10, 8, 12), device=DEV)
+    gwin[..., 4:8] = nd(pad(T(g["tri_up2.r"])))
+    close(nc(ops.trilinear_bwd(gwin, xd.shape, False, coff=4))[:, :3], g["tri_up2.gx"], 1e-4, 1e-5)
+    # bf16 storage
+    yb = ops.trilinear_fwd(torch.cat([xd, xd], -1).bfloat16(), (6, 10, 8), False)
+    relclose(nc(yb)[:, :3], T(g["tri_up2.y"]), 1e-2, "tri bf16")
 
 
 def test_pointwise():
