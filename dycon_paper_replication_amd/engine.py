@@ -142,6 +142,7 @@ class Engine:
         self.gen = 0                 # bump whenever parameter values change (invalidates packed weights)
         self._packed = {}
         self._jobs, self._jobs_dev, self._packed_gen = [], None, -1
+        self.on_param_grads = None   # optional callback(name): called in backward once a layer's parameter gradients are enqueued
         self.tape = []
         self.G = {}
 
@@ -251,6 +252,8 @@ class Engine:
                     ops.conv_wgrad(gy, x, gw, CONV_K2S2, 1, 8, Cout * 8)
                 else:                  # bias gradient = column sums of gy, fused into the wgrad pass
                     ops.conv_wgrad(x, gy, gw, mode, 1 if T > 1 else 0, T, Cin * T, dbias=gb)
+                if self.on_param_grads is not None:
+                    self.on_param_grads(name + ".weight")      # this layer's gradients are enqueued (DDP bucket trigger)
                 if not need_gx:
                     return
                 cur = self.G.get(id(x))
@@ -313,6 +316,8 @@ class Engine:
                 dg = self.g[prefix + ".weight"] if gamma is not None else None
                 db = self.g[prefix + ".bias"] if beta is not None else None
                 gz = ops.norm_bwd(z, False, gy, stats, Nb, V, C, G, gamma, beta, relu, dg, db, chan_scale=chan_scale)
+                if self.on_param_grads is not None and gamma is not None:
+                    self.on_param_grads(prefix + ".weight")
                 self._give(z, gz)
             self.tape.append(bwd)
         return y

@@ -64,6 +64,7 @@ class TrainConfig:
     dtype: torch.dtype = torch.bfloat16  # activation storage of the HIP kernels (fp32 = parity mode)
     strict_nan_check: bool = True       # read the NaN/Inf flag every step, as the reference does
     global_batch_losses: bool = True    # DDP: all-reduce the Dice / FeCL-cross sums (exact global-batch semantics)
+    overlap_teacher: bool = True        # teacher forward on a second HIP stream, concurrent with the student forward
 
 
 class DyconTrainer:
@@ -129,6 +130,30 @@ class DyconTrainer:
         self.flag = torch.zeros(1, dtype=torch.int32, device=self.device)
         self.coef = torch.zeros(8, dtype=torch.float32, device=self.device)
         self.skipped_steps = 0
+        self.side = torch.cuda.Stream(device=self.device)
+        # DDP gradient buckets: contiguous arena ranges cut at parameter boundaries.  The backward writes gradients in reverse
+        # registration order, so a bucket is complete when its FIRST parameter's gradient has been enqueued; its all-reduce is
+        # issued right then and overlaps the rest of the backward (xGMI ring: 4 x ~10 MB instead of one 39 MB transfer at the end).
+        self.buckets = []
+        if self.world > 1:
+            nb = 4
+            heads = [k for k in order if offs[k] < self.n_sgd and len(spec[k]) == 5]   # conv weights: notified by the backward
+            target = self.n_sgd / nb
+            cuts = [0]
+            for k in heads:
+                if offs[k] >= target * len(cuts) and offs[k] > cuts[-1] and len(cuts) < nb:
+                    cuts.append(offs[k])
+            cuts.append(self.n_sgd)
+            by_off = {offs[k]: k for k in heads}
+            self.buckets = [(by_off[lo], lo, hi) for lo, hi in zip(cuts[:-1], cuts[1:])]
+            self._bucket_of = {name: (lo, hi) for name, lo, hi in self.buckets}
+            self._pending = []
+            self.s_eng.on_param_grads = self._on_param_grads
+
+    def _on_param_grads(self, name):
+        rng = self._bucket_of.get(name)
+        if rng is not None:
+            self._pending.append(torch.distributed.all_reduce(self.flat_g[rng[0]:rng[1]], group=self.pg, async_op=True))
 
     # ------------------------------------------------------------------ schedules (host scalars)
     def epoch_of(self, it):
@@ -164,13 +189,26 @@ class DyconTrainer:
             t_drop = DropoutSpec("philox", seed=seed, offset=(2 * it + 1) << 42) if c.teacher_mode == "train" else DropoutSpec("off")
 
         self.s_eng.repack()          # all weight packs of the step (student fwd + dgrad, teacher fwd): one launch each
-        self.t_eng.repack()
+        self.t_eng.repack()          # (on the main stream, before the side stream forks from it)
         x = volume.reshape(B, D, H, W, 1) if volume.is_contiguous() else volume.contiguous().reshape(B, D, H, W, 1)
         x_t = ops.add_noise(x, None if noise is None else noise.contiguous(), 0.1, 0.2, seed ^ 0x5DEECE66D, it << 32)  # :301-302
 
-        s_logits, s_feat, _ = self.s_eng.forward(x, training=True, record=True, dropout=s_drop, update_bn=True)   # :304
+        # The teacher forward (:305-306) is independent of the student forward (:304): it runs on a second HIP stream so the
+        # small, launch-latency-bound kernels of the deep levels (6^3, 12^3: 50-100 workgroups on 256 CUs) of the two nets overlap.
         t_train = c.teacher_mode == "train"
-        t_logits, t_feat, _ = self.t_eng.forward(x_t, training=t_train, record=False, dropout=t_drop, update_bn=t_train)  # :305-306
+        main = torch.cuda.current_stream()
+        if c.overlap_teacher:
+            self.side.wait_stream(main)
+            with torch.cuda.stream(self.side):
+                t_logits, t_feat, _ = self.t_eng.forward(x_t, training=t_train, record=False, dropout=t_drop, update_bn=t_train)
+            x_t.record_stream(self.side)
+        s_logits, s_feat, _ = self.s_eng.forward(x, training=True, record=True, dropout=s_drop, update_bn=True)   # :304
+        if c.overlap_teacher:
+            main.wait_stream(self.side)
+            t_logits.record_stream(main)
+            t_feat.record_stream(main)
+        else:
+            t_logits, t_feat, _ = self.t_eng.forward(x_t, training=t_train, record=False, dropout=t_drop, update_bn=t_train)
 
         # ---- losses (:308-357)
         world = self.world
@@ -207,8 +245,11 @@ class DyconTrainer:
         self.s_eng.backward(g_logits, g_feat)
 
         # ---- all-reduce, clip, SGD, EMA (:368-372)
-        if world > 1:
-            torch.distributed.all_reduce(self.flat_g, group=self.pg)
+        if world > 1:      # bucketed all-reduces were issued during the backward (see __init__); wait for them here
+            assert len(self._pending) == len(self.buckets), "a gradient bucket was never triggered"
+            for h in self._pending:
+                h.wait()
+            self._pending = []
         self.sumsq.zero_()
         ops.sumsq(self.flat_g[: self.n_sgd], self.sumsq)
         alpha = min(1 - 1 / (it + 1), c.ema_decay)
