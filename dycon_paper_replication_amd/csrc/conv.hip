@@ -1317,7 +1317,7 @@ extern "C" size_t dycon_colsum_workspace(long long rows, int C);
 extern "C" int dycon_colsum(const void* x, int dtype, float* out, long long rows, int C, float* workspace, size_t ws_bytes,
                             dycon_stream_t stream);
 
-// k=3 bf16 plan: tiles and voxel-tile splits (partials capped at ~24 MB)
+// k=3 bf16 plan: tiles and voxel-tile splits
 struct WgradK3Plan { int tilesZ, tilesY, tilesX, nTiles, gx, nCoBlk, NT, splits; };
 static WgradK3Plan wgrad_k3_plan(int B, int D, int H, int W, int Cin, int Cout) {
     WgradK3Plan p;
@@ -1328,7 +1328,7 @@ static WgradK3Plan wgrad_k3_plan(int B, int D, int H, int W, int Cin, int Cout) 
     p.gx = ((Cin + 15) / 16) * p.nCoBlk;
     const long long L = 27LL * Cin * Cout;
     long long s = 2048 / p.gx;
-    const long long cap = (24LL << 20) / (4 * L);
+    const long long cap = (24LL << 20) / (4 * L) > 0 ? (24LL << 20) / (4 * L) : 1;   // partial slabs capped at ~24 MB (fewer splits = fewer workgroups = slower: measured)
     if (s > cap) s = cap;
     if (s > p.nTiles) s = p.nTiles;
     if (s < 1) s = 1;
