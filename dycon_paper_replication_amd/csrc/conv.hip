@@ -637,66 +637,68 @@ __global__ __launch_bounds__(256, 2) void wgrad_k3_bf16_kernel(const bf16* __res
     for (int j = 0; j < NT; ++j) bsum[j] = 0.f;
     const bool do_bias = bias_part != nullptr && ci0 == 0 && wave == 0;
 
-    for (int tile = blockIdx.y; tile < nTiles; tile += gridDim.y) {
-        int r = tile;
-        const int tx = r % tilesX; r /= tilesX;
-        const int ty = r % tilesY; r /= tilesY;
-        const int tz = r % tilesZ;
-        const int b = r / tilesZ;
+    // Register-staged pipeline over this workgroup's tiles: the global loads of tile i+1 are issued before the MFMAs of tile i
+    // and written to LDS after the barrier that retires tile i (the X halo and G tile of the next tile are in flight while
+    // the matrix cores work).  CIN1 (first layer, one input channel): channel 0 carries x, channels 1..15 are zero.
+    constexpr int NSX = CIN1 ? (WG_NH + 255) / 256 : (WG_NH * 2 + 255) / 256;
+    constexpr int NSG = WG_NV * (CB / 8) / 256 > 0 ? WG_NV * (CB / 8) / 256 : 1;
+    uint4 sx[NSX], sg[NSG];
+    auto load_tile = [&](int tile) {
+        int rr = tile;
+        const int tx = rr % tilesX; rr /= tilesX;
+        const int ty = rr % tilesY; rr /= tilesY;
+        const int tz = rr % tilesZ;
+        const int b = rr / tilesZ;
         const int z0 = tz * WG_TZ, y0 = ty * WG_TY, x0 = tx * WG_TX;
+#pragma unroll
+        for (int it = 0; it < NSX; ++it) {
+            const int e = threadIdx.x + 256 * it;
+            const int hv = CIN1 ? e : e >> 1, half = CIN1 ? 0 : e & 1;
+            const int hx = hv % WG_HX, hy = (hv / WG_HX) % WG_HY, hz = hv / (WG_HX * WG_HY);
+            const int z = z0 + hz - 1, y = y0 + hy - 1, x = x0 + hx - 1;
+            sx[it] = make_uint4(0, 0, 0, 0);
+            if (hv < WG_NH && (unsigned)z < (unsigned)D && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W) {
+                if (CIN1) sx[it].x = reinterpret_cast<const unsigned short*>(X)[(((long long)b * D + z) * H + y) * W + x];
+                else sx[it] = *reinterpret_cast<const uint4*>(X + ((((long long)b * D + z) * H + y) * W + x) * Cin + ci0 + 8 * half);
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < NSG; ++it) {
+            const int e = threadIdx.x + 256 * it;
+            const int v8 = e % (CB / 8), vv = e / (CB / 8);
+            const int vx = vv % WG_TX, vy = (vv / WG_TX) % WG_TY, vz = vv / (WG_TX * WG_TY);
+            const int z = z0 + vz, y = y0 + vy, x = x0 + vx;
+            sg[it] = make_uint4(0, 0, 0, 0);
+            if (e < WG_NV * (CB / 8) && z < D && y < H && x < W && co0 + 8 * v8 < Cout)
+                sg[it] = *reinterpret_cast<const uint4*>(GY + ((((long long)b * D + z) * H + y) * W + x) * Cout + co0 + 8 * v8);
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int it = 0; it < NSX; ++it) {
+            const int e = threadIdx.x + 256 * it;
+            if (CIN1) {
+                if (e < WG_NH) {
+                    *reinterpret_cast<uint4*>(Xh + e * 16) = sx[it];
+                    *reinterpret_cast<uint4*>(Xh + e * 16 + 8) = make_uint4(0, 0, 0, 0);
+                }
+            } else if (e < WG_NH * 2) {
+                *reinterpret_cast<uint4*>(Xh + (e >> 1) * 16 + 8 * (e & 1)) = sx[it];
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < NSG; ++it) {
+            const int e = threadIdx.x + 256 * it;
+            if (e < WG_NV * (CB / 8)) *reinterpret_cast<uint4*>(Gt + (e / (CB / 8)) * CB + 8 * (e % (CB / 8))) = sg[it];
+        }
+    };
+
+    if ((int)blockIdx.y < nTiles) load_tile(blockIdx.y);
+    for (int tile = blockIdx.y; tile < nTiles; tile += gridDim.y) {
         __syncthreads();   // previous tile fully consumed
-        // ---- stage X halo: 360 voxels x 32 B (two 16-B pieces each).  CIN1 (first layer, one input channel):
-        //      channel 0 carries x, channels 1..15 are zero, so the same MFMA body yields dW[:, 0, :]
-        if (CIN1) {
-            for (int hv = threadIdx.x; hv < WG_NH; hv += 256) {
-                const int hx = hv % WG_HX, hy = (hv / WG_HX) % WG_HY, hz = hv / (WG_HX * WG_HY);
-                const int z = z0 + hz - 1, y = y0 + hy - 1, x = x0 + hx - 1;
-                unsigned v0 = 0;
-                if ((unsigned)z < (unsigned)D && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W)
-                    v0 = reinterpret_cast<const unsigned short*>(X)[(((long long)b * D + z) * H + y) * W + x];
-                *reinterpret_cast<uint4*>(Xh + hv * 16) = make_uint4(v0, 0, 0, 0);
-                *reinterpret_cast<uint4*>(Xh + hv * 16 + 8) = make_uint4(0, 0, 0, 0);
-            }
-        } else {
-            constexpr int NSX = (WG_NH * 2 + 255) / 256;
-            uint4 sx[NSX];
-#pragma unroll
-            for (int it = 0; it < NSX; ++it) {
-                const int e = threadIdx.x + 256 * it;
-                const int hv = e >> 1, half = e & 1;
-                const int hx = hv % WG_HX, hy = (hv / WG_HX) % WG_HY, hz = hv / (WG_HX * WG_HY);
-                const int z = z0 + hz - 1, y = y0 + hy - 1, x = x0 + hx - 1;
-                sx[it] = make_uint4(0, 0, 0, 0);
-                if (e < WG_NH * 2 && (unsigned)z < (unsigned)D && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W)
-                    sx[it] = *reinterpret_cast<const uint4*>(X + ((((long long)b * D + z) * H + y) * W + x) * Cin + ci0 + 8 * half);
-            }
-#pragma unroll
-            for (int it = 0; it < NSX; ++it) {
-                const int e = threadIdx.x + 256 * it;
-                if (e < WG_NH * 2) *reinterpret_cast<uint4*>(Xh + (e >> 1) * 16 + 8 * (e & 1)) = sx[it];
-            }
-        }
-        // ---- stage G tile: 128 voxels x CB channels (all loads first, then the LDS writes)
-        {
-            constexpr int NSG = WG_NV * (CB / 8) / 256 > 0 ? WG_NV * (CB / 8) / 256 : 1;
-            uint4 sg[NSG];
-#pragma unroll
-            for (int it = 0; it < NSG; ++it) {
-                const int e = threadIdx.x + 256 * it;
-                const int v8 = e % (CB / 8), vv = e / (CB / 8);
-                const int vx = vv % WG_TX, vy = (vv / WG_TX) % WG_TY, vz = vv / (WG_TX * WG_TY);
-                const int z = z0 + vz, y = y0 + vy, x = x0 + vx;
-                sg[it] = make_uint4(0, 0, 0, 0);
-                if (e < WG_NV * (CB / 8) && z < D && y < H && x < W && co0 + 8 * v8 < Cout)
-                    sg[it] = *reinterpret_cast<const uint4*>(GY + ((((long long)b * D + z) * H + y) * W + x) * Cout + co0 + 8 * v8);
-            }
-#pragma unroll
-            for (int it = 0; it < NSG; ++it) {
-                const int e = threadIdx.x + 256 * it;
-                if (e < WG_NV * (CB / 8)) *reinterpret_cast<uint4*>(Gt + (e / (CB / 8)) * CB + 8 * (e % (CB / 8))) = sg[it];
-            }
-        }
+        store_tile();
         __syncthreads();
+        if (tile + (int)gridDim.y < nTiles) load_tile(tile + gridDim.y);
         // ---- 4 k-steps of 32 voxels: lane group kg owns x-row (z, y) = ((4s+kg)>>2, (4s+kg)&3), voxels x = 0..7
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
