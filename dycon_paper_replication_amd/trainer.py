@@ -6,7 +6,8 @@
 Everything between the input tensors and the updated arenas is HIP kernels from libdycon_hip.so
 enqueued on the current stream; the host only computes the reference's scalar schedules
 (adaptive beta, consistency ramp, FeCL threshold ramp, EMA alpha, poly LR).  The only device->host
-read is the reference's own NaN/Inf guard (:360-362), one int per step (``strict_nan_check``).
+read is the reference's own NaN/Inf guard (:360-362), one int per step (``strict_nan_check``), copied
+out right after the loss and waited for at the end of the step (the backward is already queued).
 
 Multi-GPU (one process per GPU, ``torch.distributed`` backend "nccl" == RCCL over xGMI): the batch
 is sharded [labelled | unlabelled] per rank; one all-reduce of the flat gradient arena after the
@@ -130,6 +131,10 @@ class DyconTrainer:
         self.flag = torch.zeros(1, dtype=torch.int32, device=self.device)
         self.coef = torch.zeros(8, dtype=torch.float32, device=self.device)
         self.skipped_steps = 0
+        # the NaN/Inf flag is final once step_loss has run: it is copied to pinned host memory right there and read at the end
+        # of the step, when the copy has long completed -- the host never waits for the backward, the GPU never runs dry
+        self.flag_host = torch.zeros(1, dtype=torch.int32).pin_memory()
+        self.flag_evt = torch.cuda.Event()
         self.side = torch.cuda.Stream(device=self.device)
         # DDP gradient buckets: contiguous arena ranges cut at parameter boundaries.  The backward writes gradients in reverse
         # registration order, so a bucket is complete when its FIRST parameter's gradient has been enqueued; its all-reduce is
@@ -233,6 +238,9 @@ class DyconTrainer:
         dice_kind = 0 if c.dice_variant == "fg" else 1
         cons_kind = 0 if c.consistency_type == "mse" else 1
         out = ops.step_loss(vals, f_loss, c.l_weight, cw, c.u_weight, dice_kind, cons_kind, self.flag)   # :355-362
+        if c.strict_nan_check:
+            self.flag_host.copy_(self.flag, non_blocking=True)
+            self.flag_evt.record()
 
         # ---- backward (:364-365).  coef = d total / d (ce, dice_fg, dice_mc, cons, uncl | fecl).
         # Means over equal shards (CE, cons, UnCL, FeCL student part) become global through the 1/world arena average;
@@ -262,7 +270,8 @@ class DyconTrainer:
 
         skipped = False
         if c.strict_nan_check:
-            skipped = bool(self.flag.item())     # the reference's own per-step sync (:360)
+            self.flag_evt.synchronize()          # the reference's own per-step check (:360); see __init__
+            skipped = bool(self.flag_host[0])
         if skipped:
             self.skipped_steps += 1              # `continue`: no update happened, iter_num unchanged
         else:

@@ -1,0 +1,50 @@
+"""Per-op timing of the V-Net's norm / conv launches at the bench shapes (B = 4, bf16).  Back-to-back launches on one
+stream, HIP events: the figure includes the launch gaps, which is what a step pays.  usage: op_micro.py [reps]"""
+import sys
+
+import torch
+
+sys.path.insert(0, __file__.rsplit("/", 2)[0])
+from dycon_paper_replication_amd import ops
+from dycon_paper_replication_amd._lib import CONV_K3
+
+reps = int(sys.argv[1]) if len(sys.argv) > 1 else 30
+dev = "cuda:0"
+B = 4
+
+
+def timeit(fn):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps * 1e3
+
+
+def both(name, fn, nbytes=0, flops=0):
+    us = timeit(fn)
+    print(f"{name:44s} {us:8.1f} us   {nbytes / us / 1e3:8.1f} GB/s   {flops / us / 1e6:8.1f} TFLOP/s", flush=True)
+
+
+for S, C in ((96, 16), (48, 32), (24, 64), (12, 128), (6, 256)):
+    V = S ** 3
+    x = torch.randn(B, S, S, S, C, device=dev).bfloat16()
+    gy = torch.randn(B, S, S, S, C, device=dev).bfloat16()
+    gamma, beta = torch.ones(C, device=dev), torch.zeros(C, device=dev)
+    dg, db = torch.empty(C, device=dev), torch.empty(C, device=dev)
+    y, stats = ops.norm_fwd(x, B, V, C, 16, gamma, beta, True)
+    nb = x.numel() * 2
+    both(f"norm_fwd GN {C}ch @{S}^3", lambda: ops.norm_fwd(x, B, V, C, 16, gamma, beta, True), 3 * nb)
+    both(f"norm_bwd GN {C}ch @{S}^3", lambda: ops.norm_bwd(x, False, gy, stats, B, V, C, 16, gamma, beta, True, dg, db), 5 * nb)
+    w = torch.randn(C, C, 3, 3, 3, device=dev) * 0.02
+    b = torch.zeros(C, device=dev)
+    if ops.conv_uses_lds(x, C, C) or C >= 64:
+        wf = ops.pack_bfrag(w, torch.bfloat16, 27, C, C, C, 1, 27, 0, C * 27)
+        both(f"conv k3 {C}->{C} @{S}^3", lambda: ops.conv_gemm(x, wf, b, CONV_K3, C, C), 2 * nb, 2 * B * V * 27 * C * C)
+    gw, gb = torch.empty_like(w), torch.empty_like(b)
+    both(f"wgrad k3 {C}->{C} @{S}^3", lambda: ops.conv_wgrad(x, gy, gw, CONV_K3, 1, 27, C * 27, dbias=gb), 2 * nb, 2 * B * V * 27 * C * C)
