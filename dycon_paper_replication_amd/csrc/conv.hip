@@ -272,7 +272,7 @@ constexpr int CL_HZ = CL_TZ + 2, CL_HY = CL_TY + 2, CL_HX = CL_TX + 2;
 constexpr int CL_NH = CL_HZ * CL_HY * CL_HX;     // 600 halo voxels
 constexpr int CL_NV = CL_TZ * CL_TY * CL_TX;     // 256 voxels = 16 m-tiles
 
-template <int CK, int NTB, int WM, bool CIN1 = false>
+template <int CK, int NTB, int WM>
 __global__ __launch_bounds__(256) void conv_k3_lds_kernel(const bf16* __restrict__ X, const bf16* __restrict__ Wf,
                                                           const float* __restrict__ bias, bf16* __restrict__ Y, int B, int D, int H,
                                                           int W, int Cin, int Cout, int NT, int tilesZ, int tilesY, int tilesX,
@@ -313,7 +313,7 @@ __global__ __launch_bounds__(256) void conv_k3_lds_kernel(const bf16* __restrict
         const int v = (wm * MTW + m) * 16 + r;                 // voxel index inside the tile: (z, y, x) = (v/64, (v/8)%8, v%8)
         vbase[m] = (((v >> 6) * CL_HY + ((v >> 3) & 7)) * RP + (v & 7)) * VS;
     }
-    const int nChunks = CIN1 ? 1 : Cin / CK;
+    const int nChunks = Cin / CK;
     constexpr int NKS = CK == 32 ? 27 : 14;                    // MFMA k-steps (32 wide) per chunk
     constexpr int GRP = CK == 32 ? 9 : 7;                      // k-steps per B group
     constexpr int NG = NKS / GRP;                              // groups per chunk (3 or 2)
@@ -335,11 +335,7 @@ __global__ __launch_bounds__(256) void conv_k3_lds_kernel(const bf16* __restrict
             const int z = z0 + hz - 1, y = y0 + hy - 1, x = x0 + hx - 1;
             stgH[it] = make_uint4(0, 0, 0, 0);
             const bool in = e < CL_NH * PPV && (unsigned)z < (unsigned)D && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
-            if (CIN1) {
-                // first layer (one input channel): channel 0 of the 16-wide LDS rows carries x, channels 1..15 are ZERO, so
-                // the packed weights may alias channel 0 for every c (pack with s_c = 0): 0 * w contributes nothing
-                if (in && pc == 0) stgH[it].x = reinterpret_cast<const unsigned short*>(X)[(((long long)b * D + z) * H + y) * W + x];
-            } else if (in) {
+            if (in) {
                 stgH[it] = *reinterpret_cast<const uint4*>(X + ((((long long)b * D + z) * H + y) * W + x) * Cin + ch * CK + 8 * pc);
             }
         }
@@ -460,6 +456,341 @@ __global__ __launch_bounds__(256) void conv_k3_lds_kernel(const bf16* __restrict
             for (int k = 0; k < 8; ++k) o.set(k, o.get(k) + old.get(k));
         }
         st16(yp, o);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// The 96^3 level (16 channels wide, where most of the step's bytes live): persistent, weight-stationary k=3 kernels.
+//
+// conv_k3_lds_kernel above pays, per 256-voxel tile, an un-overlapped HBM round trip for the halo, a restage of the whole
+// weight tensor through LDS and a B-fragment LDS read per MFMA.  At 16 channels the complete weight tensor is 14 B fragments
+// = 56 VGPRs, so here
+//   * every wave keeps ALL weights in registers for the lifetime of the workgroup (no B traffic at all after the prologue),
+//   * a workgroup walks many tiles (grid = 2 workgroups per CU) and the next tile's halo is already in flight in registers
+//     while the matrix cores work on the current one (register-staged: written to LDS behind the barrier that retires it),
+//   * the output tile leaves through its own LDS staging area, so its 16-byte global stores overlap the next tile's MFMAs,
+//   * each XCD owns one contiguous range of tiles: the 2.3x halo overlap between neighbouring tiles is served by that XCD's L2.
+// LDS A-fragment reads (one ds_read_b128 per MFMA, the array's limit) and the HBM stream are then the two bounds.
+// ------------------------------------------------------------------------------------------------
+constexpr int P16_RP = 16;                                  // x-row pitch of the halo image in voxels (conflict-free, see above)
+constexpr int P16_XH = CL_HZ * CL_HY * P16_RP * 16;         // halo image, bf16 elements (30 KB)
+#ifndef P16_WGS
+#define P16_WGS 2                                            // workgroups per CU (register budget 256 VGPRs)
+#endif
+#ifndef P16_DEPTH
+#define P16_DEPTH 2                                          // halo tiles in flight per workgroup
+#endif
+
+// tiles of this workgroup: its XCD's contiguous range (workgroups are dealt to XCDs round-robin), walked with stride gridDim.x/8
+__device__ __forceinline__ void xcd_tile_range(int nTiles, int& first, int& end, int& stride) {
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int per = (nTiles + 7) >> 3;
+    stride = gridDim.x >> 3;
+    first = xcd * per + slot;
+    end = min(nTiles, (xcd + 1) * per);
+}
+
+// 16-byte global store the compiler's s_waitcnt bookkeeping does not see.  On gfx9-family targets loads and stores share vmcnt and
+// may retire out of order with respect to each other, so with a store pending the compiler waits vmcnt(0) before the first use of
+// ANY earlier load -- which would drain the halo prefetches that are meant to stay in flight across tiles.  With the stores hidden
+// only loads are tracked (they retire in order) and the compiler emits counted vmcnt(N); the hardware counter additionally holds
+// these stores, which can only make a counted wait longer, never shorter.  The store reads its data VGPRs when it issues.
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void st16_untracked(void* p, const uint4& v) {
+    const u32x4 q = {v.x, v.y, v.z, v.w};
+    asm volatile("global_store_dwordx4 %0, %1, off" : : "v"(p), "v"(q) : "memory");
+}
+
+struct TileGeo {            // wave-uniform (SGPR) description of one tile
+    long long org;          // element offset of voxel (b, z0, y0, x0), 16 channels per voxel
+    int z0, y0, x0;
+    int inner;              // the whole 6x10x10 halo lies inside the volume: no clamping, no zero padding
+};
+
+template <int DEPTH, bool ACC>
+__global__ __launch_bounds__(256, P16_WGS) void conv_k3_p16_kernel(const bf16* __restrict__ X, const bf16* __restrict__ Wf,
+                                                                   const float* __restrict__ bias, bf16* __restrict__ Y, int B,
+                                                                   int D, int H, int W, int tilesZ, int tilesY, int tilesX,
+                                                                   int nTiles) {
+    constexpr int OS = 16 + 8;                               // output staging row stride (elements): +16 B against conflicts
+    __shared__ __attribute__((aligned(16))) unsigned short Xh[P16_XH];
+    __shared__ __attribute__((aligned(16))) unsigned short Ot[CL_NV * OS];
+    int tile, t_end, t_stride;
+    xcd_tile_range(nTiles, tile, t_end, t_stride);
+    if (tile >= t_end) return;                               // (uniform) nothing to do: keeps every wait below on a single path
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 15, kg = lane >> 4;
+    bf16x8 bfr[14];                                          // K = 27 taps x 16 channels = 14 k-steps of 32 (tap 27 = zero padding)
+#pragma unroll
+    for (int ks = 0; ks < 14; ++ks)
+        bfr[ks] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(Wf + ((long long)ks * 64 + lane) * 8));
+    const float bv = bias ? bias[r] : 0.f;
+    // A-fragment addresses: wave w owns z-slice w of the tile; its m-tile m is the y-row pair 2m, 2m+1 (16 voxels), so the four
+    // m-tiles differ by a constant (an immediate offset of the ds_read) and one address register per k-step suffices.
+    // This lane's tap of k-step ks is 2 ks + (kg >> 1); tap 27 is padding (zero weights, reads tap 26).
+    auto tap_elems = [](int t) { return ((t / 9) * CL_HY * P16_RP + ((t / 3) % 3) * P16_RP + (t % 3)) * 16; };
+    constexpr int MSTEP = 2 * P16_RP * 16;                   // elements between consecutive m-tiles
+    int abase[14];
+    {
+        const int vb = ((wave * CL_HY + (r >> 3)) * P16_RP + (r & 7)) * 16 + 8 * (kg & 1);
+#pragma unroll
+        for (int ks = 0; ks < 14; ++ks) {
+            const int t0 = 2 * ks, t1 = 2 * ks + 1 > 26 ? 26 : 2 * ks + 1;
+            abase[ks] = vb + ((kg >> 1) ? tap_elems(t1) : tap_elems(t0));
+        }
+    }
+
+    // Tile-independent geometry of this thread's NST halo pieces and 2 output pieces, computed ONCE: with 56 MFMAs per wave and
+    // tile, per-tile index arithmetic (divisions by the tile counts, piece -> voxel decoding, 64-bit address products) would
+    // otherwise cost several times the matrix work in VALU/SALU issue slots (measured: 310 VALU + 218 SALU per tile).
+    // Pieces past the 1200th (threads >= 176 of the fifth round) duplicate piece 1199: same address, same LDS slot, same value.
+    constexpr int NST = (CL_NH * 2 + 255) / 256;             // 16-byte halo pieces per thread (5)
+    int rel[NST], lofs[NST], hco[NST];
+#pragma unroll
+    for (int it = 0; it < NST; ++it) {
+        const int e = min((int)threadIdx.x + 256 * it, CL_NH * 2 - 1);
+        const int hv = e >> 1, pc = e & 1;
+        const int hx = hv % CL_HX, hy = (hv / CL_HX) % CL_HY, hz = hv / (CL_HX * CL_HY);
+        rel[it] = (((hz - 1) * H + (hy - 1)) * W + (hx - 1)) * 16 + 8 * pc;      // element offset from the tile's origin voxel
+        lofs[it] = ((hv / CL_HX) * P16_RP + hx) * 16 + 8 * pc;                   // element offset in the LDS image
+        hco[it] = hz | (hy << 8) | (hx << 16) | (pc << 24);
+    }
+    int orel[2], oofs[2];
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int e = threadIdx.x + 256 * it;
+        const int v = e >> 1, pc = e & 1;
+        orel[it] = (((v >> 6) * H + ((v >> 3) & 7)) * W + (v & 7)) * 16 + 8 * pc;
+        oofs[it] = v * OS + 8 * pc;
+    }
+    auto geometry = [&](int t, TileGeo& g) {                 // scalar: tile index -> origin / flags (clamped past the end)
+        t = min(t, t_end - 1);
+        const int tx = t % tilesX; t /= tilesX;
+        const int ty = t % tilesY; t /= tilesY;
+        const int tz = t % tilesZ;
+        const int b = t / tilesZ;
+        g.z0 = tz * CL_TZ; g.y0 = ty * CL_TY; g.x0 = tx * CL_TX;
+        g.org = ((((long long)b * D + g.z0) * H + g.y0) * W + g.x0) * 16;
+        g.inner = g.z0 >= 1 && g.z0 + CL_TZ < D && g.y0 >= 1 && g.y0 + CL_TY < H && g.x0 >= 1 && g.x0 + CL_TX < W;
+    };
+    // Halo loads are UNCONDITIONAL (boundary tiles read clamped, valid addresses and zero the padding when writing LDS): every wave
+    // issues exactly NST loads per tile, so the compiler's counted s_waitcnt vmcnt(N) keeps the younger tiles' loads in flight.
+    auto load_halo = [&](const TileGeo& g, uint4 (&stg)[NST]) {
+        const bf16* base = X + g.org;
+        if (g.inner) {
+#pragma unroll
+            for (int it = 0; it < NST; ++it) stg[it] = *reinterpret_cast<const uint4*>(base + rel[it]);
+        } else {
+#pragma unroll
+            for (int it = 0; it < NST; ++it) {
+                const int hz = hco[it] & 255, hy = (hco[it] >> 8) & 255, hx = (hco[it] >> 16) & 255, pc = hco[it] >> 24;
+                const int z = min(max(g.z0 + hz - 1, 0), D - 1), y = min(max(g.y0 + hy - 1, 0), H - 1), x = min(max(g.x0 + hx - 1, 0), W - 1);
+                const int dz = z - g.z0, dy = y - g.y0, dx = x - g.x0;
+                stg[it] = *reinterpret_cast<const uint4*>(base + ((dz * H + dy) * W + dx) * 16 + 8 * pc);
+            }
+        }
+    };
+    auto store_halo = [&](const TileGeo& g, const uint4 (&stg)[NST]) {
+        if (g.inner) {
+#pragma unroll
+            for (int it = 0; it < NST; ++it) *reinterpret_cast<uint4*>(Xh + lofs[it]) = stg[it];
+        } else {
+#pragma unroll
+            for (int it = 0; it < NST; ++it) {
+                const int hz = hco[it] & 255, hy = (hco[it] >> 8) & 255, hx = (hco[it] >> 16) & 255;
+                const int z = g.z0 + hz - 1, y = g.y0 + hy - 1, x = g.x0 + hx - 1;
+                const bool in = (unsigned)z < (unsigned)D && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
+                uint4 v = stg[it];
+                if (!in) v = make_uint4(0, 0, 0, 0);
+                *reinterpret_cast<uint4*>(Xh + lofs[it]) = v;
+            }
+        }
+    };
+
+    // One tile: [issue the halo loads of tile + DEPTH*stride into set `ld`] -> MFMAs from the LDS image -> barrier -> stage the
+    // output, write the halo of tile + stride (set `st`, requested DEPTH - 1 tiles ago) -> barrier -> 16-byte global stores.
+    auto one_tile = [&](int cur, TileGeo& gcur, TileGeo& gld, uint4 (&ld)[NST], const TileGeo& gst, const uint4 (&st)[NST]) {
+        geometry(cur + DEPTH * t_stride, gld);
+        load_halo(gld, ld);
+        f32x4 acc[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 14; ++ks) {
+            bf16x8 afr[4];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) afr[m] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(Xh + abase[ks] + m * MSTEP));
+#pragma unroll
+            for (int m = 0; m < 4; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[m], bfr[ks], acc[m], 0, 0, 0);
+        }
+        __syncthreads();                                     // halo image consumed; previous tile's Ot fully stored
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) Ot[((wave * 4 + m) * 16 + 4 * kg + i) * OS + r] = f32_to_bf16_bits(acc[m][i] + bv);
+        store_halo(gst, st);
+        __syncthreads();
+        const bool full = gcur.z0 + CL_TZ <= D && gcur.y0 + CL_TY <= H && gcur.x0 + CL_TX <= W;
+        bf16* ybase = Y + gcur.org;
+        if (cur < t_end) {                                   // (else: idle slot of the unrolled tail -- a clamped tile, nothing stored)
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {                 // 256 voxels x 2 pieces of 16 B
+                if (!full) {
+                    const int v = (threadIdx.x + 256 * it) >> 1;
+                    if (gcur.z0 + (v >> 6) >= D || gcur.y0 + ((v >> 3) & 7) >= H || gcur.x0 + (v & 7) >= W) continue;
+                }
+                bf16* yp = ybase + orel[it];
+                Vec16<bf16> o;
+                o.v = *reinterpret_cast<const uint4*>(Ot + oofs[it]);
+                if (ACC) {                                   // (drains the prefetches: the gradient-accumulate variant is not pipelined)
+                    const Vec16<bf16> old = ld16(yp);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) o.set(k, o.get(k) + old.get(k));
+                    st16(yp, o);
+                } else {
+                    st16_untracked(yp, o.v);
+                }
+            }
+        }
+        gcur = gst;                                          // the image now in LDS
+    };
+
+    // register sets: tile j of this workgroup's sequence travels in set j % DEPTH (with its scalar geometry)
+    uint4 s0[NST], s1[NST], s2[NST];
+    TileGeo g0, g1, g2, gcur;
+    geometry(tile, g0);
+    load_halo(g0, s0);
+    store_halo(g0, s0);                                      // (the wait for s0 also retires the weight loads)
+    gcur = g0;
+    geometry(tile + t_stride, g1);
+    load_halo(g1, s1);
+    if (DEPTH == 3) { geometry(tile + 2 * t_stride, g2); load_halo(g2, s2); }
+    __syncthreads();
+    if (DEPTH == 2) {
+        for (; tile < t_end; tile += 2 * t_stride) {         // tile j: loads j+2 into set j%2 (free since j was written), writes j+1
+            one_tile(tile, gcur, g0, s0, g1, s1);
+            one_tile(tile + t_stride, gcur, g1, s1, g0, s0);
+        }
+    } else {
+        for (; tile < t_end; tile += 3 * t_stride) {         // branch-free body: slots past the end compute a clamped tile, store nothing
+            one_tile(tile, gcur, g0, s0, g1, s1);
+            one_tile(tile + t_stride, gcur, g1, s1, g2, s2);
+            one_tile(tile + 2 * t_stride, gcur, g2, s2, g0, s0);
+        }
+    }
+}
+
+// First layer (ONE input channel -> 16 * NT): K = 27 taps, padded to a single 32-wide k-step whose A fragment is gathered
+// from a 1.2 KB scalar halo image (8 ds_read_u16 per lane and m-tile).  One MFMA per 16 voxels and n-tile: the kernel is a
+// pure HBM stream of its output (2 B in, 32 * NT B out per voxel).  wfrag = dycon_pack_bfrag(T = 27, Cin = 1).
+template <int NT>
+__global__ __launch_bounds__(256) void conv_k3_c1_kernel(const bf16* __restrict__ X, const bf16* __restrict__ Wf,
+                                                         const float* __restrict__ bias, bf16* __restrict__ Y, int B, int D, int H,
+                                                         int W, int tilesZ, int tilesY, int tilesX, int nTiles, int accumulate) {
+    constexpr int XP = 12;                                   // x-row pitch of the scalar image (elements)
+    constexpr int CB = NT * 16, OS = CB + 8;
+    __shared__ unsigned short Xs[CL_HZ * CL_HY * XP];
+    __shared__ __attribute__((aligned(16))) unsigned short Ot[CL_NV * OS];
+    const unsigned short* Xg = reinterpret_cast<const unsigned short*>(X);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 15, kg = lane >> 4;
+    bf16x8 bfr[NT];
+    float bv[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        bfr[j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(Wf + ((long long)j * 64 + lane) * 8));
+        bv[j] = bias ? bias[j * 16 + r] : 0.f;
+    }
+    int vbase[4], toffs[8];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        const int v = (wave * 4 + m) * 16 + r;
+        vbase[m] = ((v >> 6) * CL_HY + ((v >> 3) & 7)) * XP + (v & 7);
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {                            // this lane's taps 8 kg + e (taps >= 27: zero weights)
+        int t = 8 * kg + e;
+        if (t > 26) t = 26;
+        toffs[e] = ((t / 9) * CL_HY + (t / 3) % 3) * XP + t % 3;
+    }
+    constexpr int NST = (CL_NH + 255) / 256;                 // 3 scalars per thread
+    unsigned short stg[NST];
+    auto tile_origin = [&](int tile, int& b, int& z0, int& y0, int& x0) {
+        const int tx = tile % tilesX; tile /= tilesX;
+        const int ty = tile % tilesY; tile /= tilesY;
+        const int tz = tile % tilesZ;
+        b = tile / tilesZ;
+        z0 = tz * CL_TZ; y0 = ty * CL_TY; x0 = tx * CL_TX;
+    };
+    auto load_halo = [&](int tile) {
+        int b, z0, y0, x0;
+        tile_origin(tile, b, z0, y0, x0);
+#pragma unroll
+        for (int it = 0; it < NST; ++it) {
+            const int hv = threadIdx.x + 256 * it;
+            const int hx = hv % CL_HX, hy = (hv / CL_HX) % CL_HY, hz = hv / (CL_HX * CL_HY);
+            const int z = z0 + hz - 1, y = y0 + hy - 1, x = x0 + hx - 1;
+            stg[it] = 0;
+            if (hv < CL_NH && (unsigned)z < (unsigned)D && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W)
+                stg[it] = Xg[(((long long)b * D + z) * H + y) * W + x];
+        }
+    };
+    auto store_halo = [&]() {
+#pragma unroll
+        for (int it = 0; it < NST; ++it) {
+            const int hv = threadIdx.x + 256 * it;
+            if (hv < CL_NH) Xs[(hv / CL_HX) * XP + hv % CL_HX] = stg[it];
+        }
+    };
+
+    int tile, t_end, t_stride;
+    xcd_tile_range(nTiles, tile, t_end, t_stride);
+    if (tile < t_end) { load_halo(tile); store_halo(); }
+    __syncthreads();
+    for (; tile < t_end; tile += t_stride) {
+        const bool has_next = tile + t_stride < t_end;
+        if (has_next) load_halo(tile + t_stride);
+        f32x4 acc[4][NT];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            unsigned w[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                w[e] = (unsigned)Xs[vbase[m] + toffs[2 * e]] | ((unsigned)Xs[vbase[m] + toffs[2 * e + 1]] << 16);
+            const bf16x8 afr = __builtin_bit_cast(bf16x8, make_uint4(w[0], w[1], w[2], w[3]));
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+                acc[m][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr, bfr[j], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    Ot[((wave * 4 + m) * 16 + 4 * kg + i) * OS + j * 16 + r] = f32_to_bf16_bits(acc[m][j][i] + bv[j]);
+        if (has_next) store_halo();
+        __syncthreads();
+        int b, z0, y0, x0;
+        tile_origin(tile, b, z0, y0, x0);
+        constexpr int PPR = CB / 8;
+#pragma unroll
+        for (int it = 0; it < PPR; ++it) {
+            const int e = threadIdx.x + 256 * it;
+            const int v = e / PPR, pc = e % PPR;
+            const int z = z0 + (v >> 6), y = y0 + ((v >> 3) & 7), x = x0 + (v & 7);
+            if (z >= D || y >= H || x >= W) continue;
+            bf16* yp = Y + ((((long long)b * D + z) * H + y) * W + x) * CB + 8 * pc;
+            Vec16<bf16> o;
+            o.v = *reinterpret_cast<const uint4*>(Ot + v * OS + 8 * pc);
+            if (accumulate) {
+                const Vec16<bf16> old = ld16(yp);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) o.set(k, o.get(k) + old.get(k));
+            }
+            st16(yp, o);
+        }
     }
 }
 
@@ -1198,26 +1529,39 @@ extern "C" int dycon_conv_gemm(const void* x, const void* wfrag, const float* bi
     DYCON_REQUIRE(x && wfrag && y, "conv_gemm: null pointer");
     DYCON_REQUIRE(B > 0 && Di > 0 && Hi > 0 && Wi > 0 && Cin > 0 && N > 0 && Cout > 0, "conv_gemm: bad shape");
     DYCON_REQUIRE(mode >= 0 && mode <= 2, "conv_gemm: bad mode %d", mode);
-    const bool first_layer_lds = dtype == DYCON_BF16 && mode == DYCON_CONV_K3 && !scatter && Cin == 1 && (long long)Di * Hi * Wi >= 13824;
+    const bool first_layer_lds = dtype == DYCON_BF16 && mode == DYCON_CONV_K3 && !scatter && Cin == 1 &&
+                                 (Cout == 16 || Cout == 32 || Cout == 64) && (long long)Di * Hi * Wi >= 13824;
     DYCON_REQUIRE(first_layer_lds || Cin % (dtype == DYCON_BF16 ? 8 : 4) == 0, "conv_gemm: Cin=%d not a multiple of the fragment width", Cin);
     DYCON_REQUIRE(N % 16 == 0, "conv_gemm: N=%d not a multiple of 16 (use dycon_conv_direct)", N);
     DYCON_REQUIRE(!scatter || (mode == DYCON_CONV_1X1 && N == 8 * Cout), "conv_gemm: scatter needs mode 1x1 and N == 8*Cout");
     DYCON_REQUIRE(scatter || N == Cout, "conv_gemm: N must equal Cout without scatter");
     DYCON_REQUIRE(mode != DYCON_CONV_K2S2 || (Di % 2 == 0 && Hi % 2 == 0 && Wi % 2 == 0), "conv_gemm: k2s2 needs even dims");
     // large spatial levels, bf16: LDS-halo kernel
-    if (dtype == DYCON_BF16 && mode == DYCON_CONV_K3 && !scatter && (Cin == 1 || Cin == 16 || Cin == 48 || Cin % 32 == 0) &&
-        (Cout == 16 || Cout == 32 || Cout % 64 == 0 || Cout % 48 == 0) && (long long)Di * Hi * Wi >= 13824) {
+    if (dtype == DYCON_BF16 && mode == DYCON_CONV_K3 && !scatter &&
+        ((Cin == 1 && (Cout == 16 || Cout == 32 || Cout == 64)) ||
+         ((Cin == 16 || Cin == 48 || Cin % 32 == 0) && (Cout == 16 || Cout == 32 || Cout % 64 == 0 || Cout % 48 == 0))) &&
+        (long long)Di * Hi * Wi >= 13824) {
         const int tz = cdiv(Di, CL_TZ), ty = cdiv(Hi, CL_TY), tx = cdiv(Wi, CL_TX);
         const int NT = Cout / 16;
         const int ntb = Cout % 64 == 0 ? 4 : (Cout % 48 == 0 ? 3 : NT);
-        dim3 grid(B * tz * ty * tx, NT / ntb);
+        const int nTiles = B * tz * ty * tx;
+        // persistent kernels of the 16-channel level: 8 XCDs x up to 64 (p16: 2 per CU) / 128 (c1) workgroups
+        if ((Cin == 16 && Cout == 16) || (Cin == 1 && (Cout == 16 || Cout == 32 || Cout == 64))) {
+            const int per_xcd = min(cdiv(nTiles, 8), Cin == 16 ? 32 * P16_WGS : 128);
+            const bf16 *xp = (const bf16*)x, *wp = (const bf16*)wfrag;
+            bf16* yp = (bf16*)y;
+            if (Cin == 16 && accumulate) conv_k3_p16_kernel<P16_DEPTH, true><<<8 * per_xcd, 256, 0, stream>>>(xp, wp, bias, yp, B, Di, Hi, Wi, tz, ty, tx, nTiles);
+            else if (Cin == 16) conv_k3_p16_kernel<P16_DEPTH, false><<<8 * per_xcd, 256, 0, stream>>>(xp, wp, bias, yp, B, Di, Hi, Wi, tz, ty, tx, nTiles);
+            else if (Cout == 16) conv_k3_c1_kernel<1><<<8 * per_xcd, 256, 0, stream>>>(xp, wp, bias, yp, B, Di, Hi, Wi, tz, ty, tx, nTiles, accumulate);
+            else if (Cout == 32) conv_k3_c1_kernel<2><<<8 * per_xcd, 256, 0, stream>>>(xp, wp, bias, yp, B, Di, Hi, Wi, tz, ty, tx, nTiles, accumulate);
+            else conv_k3_c1_kernel<4><<<8 * per_xcd, 256, 0, stream>>>(xp, wp, bias, yp, B, Di, Hi, Wi, tz, ty, tx, nTiles, accumulate);
+            DYCON_LAUNCH_CHECK();
+            return DYCON_OK;
+        }
+        dim3 grid(nTiles, NT / ntb);
 #define DYCON_CL(CKV, NTBV, WMV) \
     conv_k3_lds_kernel<CKV, NTBV, WMV><<<grid, 256, 0, stream>>>((const bf16*)x, (const bf16*)wfrag, bias, (bf16*)y, B, Di, Hi, Wi, Cin, Cout, NT, tz, ty, tx, accumulate)
-        if (Cin == 1) {   // wfrag packed as Cin = 16 with channel stride 0 (see the kernel)
-            if (ntb == 1) conv_k3_lds_kernel<16, 1, 4, true><<<grid, 256, 0, stream>>>((const bf16*)x, (const bf16*)wfrag, bias, (bf16*)y, B, Di, Hi, Wi, 1, Cout, NT, tz, ty, tx, accumulate);
-            else if (ntb == 2) conv_k3_lds_kernel<16, 2, 4, true><<<grid, 256, 0, stream>>>((const bf16*)x, (const bf16*)wfrag, bias, (bf16*)y, B, Di, Hi, Wi, 1, Cout, NT, tz, ty, tx, accumulate);
-            else conv_k3_lds_kernel<16, 4, 2, true><<<grid, 256, 0, stream>>>((const bf16*)x, (const bf16*)wfrag, bias, (bf16*)y, B, Di, Hi, Wi, 1, Cout, NT, tz, ty, tx, accumulate);
-        } else if (Cin == 16 || Cin == 48) {
+        if (Cin == 16 || Cin == 48) {
             if (ntb == 1) DYCON_CL(16, 1, 4); else if (ntb == 2) DYCON_CL(16, 2, 4); else if (ntb == 3) DYCON_CL(16, 3, 4); else DYCON_CL(16, 4, 2);
         } else {
             if (ntb == 1) DYCON_CL(32, 1, 4); else if (ntb == 2) DYCON_CL(32, 2, 4); else if (ntb == 3) DYCON_CL(32, 3, 4); else DYCON_CL(32, 4, 2);

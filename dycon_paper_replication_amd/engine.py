@@ -224,10 +224,10 @@ class Engine:
         gq = 8 if dtype == torch.bfloat16 else 4
         skinny = (Cin % gq != 0) or (Cout % 16 != 0)
         out_dtype = out_dtype or dtype
-        first_lds = (kind == "k3" and Cin == 1 and dtype == torch.bfloat16 and Cout % 16 == 0 and out_dtype == dtype
+        first_lds = (kind == "k3" and Cin == 1 and dtype == torch.bfloat16 and Cout in (16, 32, 64) and out_dtype == dtype
                      and x.shape[1] * x.shape[2] * x.shape[3] >= 13824)
-        if first_lds:   # first layer on the matrix cores: weights packed as 16 aliased channels (stride 0), see dycon_hip.h
-            wf = self._pk((name, "f1"), "frag", w, 27, 16, Cout, Cout, 1, 0, 0, 27)
+        if first_lds:   # first layer on the matrix cores: K = 27 taps in one 32-wide k-step (conv_k3_c1_kernel), see dycon_hip.h
+            wf = self._pk((name, "f1"), "frag", w, 27, 1, Cout, Cout, 1, 27, 0, 27)
             y = ops.conv_gemm(x, wf, b, CONV_K3, Cout, Cout)
         elif skinny:
             assert kind in ("k3", "1x1"), "skinny path only for the first conv and the 1x1 heads"

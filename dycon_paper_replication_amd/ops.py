@@ -122,8 +122,11 @@ def pack_batch(jobs_dev, njobs, blocks_per_job=8):
 def conv_uses_lds(x, Cin, Cout):
     """True when dycon_conv_gemm routes a k=3 conv of this shape to the LDS-halo kernel (bf16, >= 24^3 voxels)."""
     _, D, H, W, _ = x.shape
-    return (x.dtype == torch.bfloat16 and (Cin in (1, 16, 48) or Cin % 32 == 0)
-            and (Cout in (16, 32) or Cout % 64 == 0 or Cout % 48 == 0) and D * H * W >= 13824)
+    if x.dtype != torch.bfloat16 or D * H * W < 13824:
+        return False
+    if Cin == 1:
+        return Cout in (16, 32, 64)
+    return (Cin in (16, 48) or Cin % 32 == 0) and (Cout in (16, 32) or Cout % 64 == 0 or Cout % 48 == 0)
 
 
 # ------------------------------------------------------------------ conv family

@@ -74,8 +74,8 @@ int dycon_pack_tcn(const float* w, float* out, int T, int Cin, int N, int N0, lo
  *              VNet.py:210-222 / networks/utils.py:276).
  * Replaces F.conv3d / F.conv_transpose3d forward and their data-gradients.
  * Needs Cin % 8 == 0 (bf16) or Cin % 4 == 0 (f32), N % 16 == 0; otherwise use *_direct.
- * Exception (bf16, k3, >= 24^3 voxels): Cin == 1 runs on the LDS-halo kernel with wfrag packed as
- * T=27, Cin=16, s_c=0 (the kernel zero-fills channels 1..15 of its staged rows); Cin == 48 (U-Net
+ * Exception (bf16, k3, >= 24^3 voxels): Cin == 1 with N in {16, 32, 64} (first layer) runs on the matrix cores
+ * with wfrag packed as T=27, Cin=1 (K = 27 taps in one 32-wide k-step); Cin == 48 (U-Net
  * decoder) runs there with wfrag packed chunk-major: three T=27, Cin=16 packs of channels [0,16), [16,32),
  * [32,48) back to back.
  * workspace (optional, dycon_conv_gemm_workspace() bytes): enables split-K for the small spatial
