@@ -256,6 +256,141 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const T* __restrict__ X,
 }
 
 // ------------------------------------------------------------------------------------------------
+// k=3 convolution at the small spatial levels (12^3, 6^3: 128 / 256 channels), bf16: LDS-tiled split-K GEMM.
+//
+// There the implicit GEMM is weight-dominated (M = B*V = 6912 or 864 rows, K = 27*Cin = 3456 .. 6912, N = 128 / 256): in the
+// gather kernel above every WAVE streams its own copy of the B fragments from L2 (13 FLOP per L2 byte).  Here a workgroup
+// owns a 64-row x 128-column tile; per 32-wide k-step the A tile (64 gathered 64-byte voxel segments, zero padding resolved
+// at staging time) and the B tile (8 packed fragments, 8 KB) are staged ONCE into double-buffered LDS and shared by the four
+// waves (2 x 2, each 32 rows x 64 columns = 8 MFMAs per k-step on 6 ds_read_b128): 43 FLOP per L2 byte, one barrier per k-step,
+// the next k-step's global loads in flight under the MFMAs.  Split-K partial slabs + ordered finish as in conv_gemm_kernel.
+// ------------------------------------------------------------------------------------------------
+constexpr int CT_BM = 64, CT_BN = 128, CT_AS = 40;          // A rows padded to 80 B: conflict-free ds_read_b128 fragments
+
+__global__ __launch_bounds__(256, 4) void conv_k3_tile_kernel(const bf16* __restrict__ X, const bf16* __restrict__ Wf,
+                                                           const float* __restrict__ bias, bf16* __restrict__ Y,
+                                                           float* __restrict__ slab, int B, int D, int H, int W, int Cin, int N,
+                                                           int NT, int nKC, int kc_per_split, int accumulate) {
+    __shared__ __attribute__((aligned(16))) unsigned short As[2][CT_BM * CT_AS];
+    __shared__ __attribute__((aligned(16))) unsigned short Bs[2][8 * 64 * 8];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 15, kg = lane >> 4;
+    const int wm = wave >> 1, wn = wave & 1;
+    const long long M = (long long)B * D * H * W;
+    const int nt0 = blockIdx.y * 8;
+    // staging role: A piece (row, 16-byte quarter of the 32-channel segment), two B pieces
+    const int arow = threadIdx.x >> 2, aq = threadIdx.x & 3;
+    const long long am = (long long)blockIdx.x * CT_BM + arow;
+    int ax, ay, az, ab;
+    {
+        long long q = am < M ? am : 0;
+        ax = (int)(q % W); q /= W;
+        ay = (int)(q % H); q /= H;
+        az = (int)(q % D);
+        ab = (int)(q / D);
+    }
+    const bool avalid = am < M;
+    const int kc0 = slab ? blockIdx.z * kc_per_split : 0;
+    const int kc1 = slab ? min(nKC, kc0 + kc_per_split) : nKC;
+    int t = (kc0 * 32) / Cin, c = kc0 * 32 - t * Cin;          // (tap, first channel) of the next k-step to request: Cin % 32 == 0
+    int kreq = kc0;                                            // k-steps are requested strictly in order
+    // Address generation is kept OFF the vector ALU (measured: 75 VALU + 50 SALU instructions per k-step against 8 MFMAs when the
+    // tap is decoded per thread): a k-step's tap offset and weight-chunk base are wave-uniform (scalar registers), the thread's own
+    // voxel / fragment-lane offsets are fixed 32-bit values, and the zero padding of all 27 taps is one precomputed bit mask.
+    unsigned vmask = 0;
+    for (int tt = 0; tt < 27; ++tt) {
+        const int zi = az + tt / 9 - 1, yi = ay + (tt / 3) % 3 - 1, xi = ax + tt % 3 - 1;
+        if (avalid && (unsigned)zi < (unsigned)D && (unsigned)yi < (unsigned)H && (unsigned)xi < (unsigned)W) vmask |= 1u << tt;
+    }
+    const unsigned aoff = (unsigned)(((((long long)ab * D + az) * H + ay) * W + ax) * Cin + 8 * aq) * 2u;   // bytes; small levels: < 2^31
+    const unsigned boff = threadIdx.x * 16u;
+    // Two register stages keep the global loads of two k-steps in flight under the MFMAs of a third (more stages spill at the
+    // register budget that lets several workgroups share a CU, which hides the rest of the L2 latency).
+    struct Stage { uint4 a, b0, b1; };
+    auto request = [&](Stage& st) {
+        const int tt = min(t, 26);
+        const int dz = tt / 9, dy = (tt / 3) % 3, dx = tt % 3;                    // wave-uniform
+        const char* xs = reinterpret_cast<const char*>(X) + (((long long)((dz - 1) * H + (dy - 1)) * W + (dx - 1)) * Cin + c) * 2;
+        st.a = make_uint4(0, 0, 0, 0);
+        if ((vmask >> tt) & 1u) st.a = *reinterpret_cast<const uint4*>(xs + aoff);
+        const char* ws = reinterpret_cast<const char*>(Wf) + ((long long)min(kreq, nKC - 1) * NT + nt0) * 1024;
+        st.b0 = *reinterpret_cast<const uint4*>(ws + boff);
+        st.b1 = *reinterpret_cast<const uint4*>(ws + boff + 4096);
+        ++kreq;
+        c += 32;
+        if (c == Cin) { c = 0; ++t; }
+    };
+    auto publish = [&](const Stage& st, int buf) {
+        *reinterpret_cast<uint4*>(&As[buf][arow * CT_AS + 8 * aq]) = st.a;
+        *reinterpret_cast<uint4*>(&Bs[buf][threadIdx.x * 8]) = st.b0;
+        *reinterpret_cast<uint4*>(&Bs[buf][(threadIdx.x + 256) * 8]) = st.b1;
+    };
+    f32x4 acc[2][4];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[m][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    auto compute = [&](int buf) {
+        bf16x8 a[2], b[4];
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+            a[m] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(&As[buf][(wm * 32 + m * 16 + r) * CT_AS + 8 * kg]));
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            b[j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(&Bs[buf][((wn * 4 + j) * 64 + lane) * 8]));
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[m][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[m], b[j], acc[m][j], 0, 0, 0);
+    };
+
+    Stage s0, s1;
+    request(s0);
+    publish(s0, 0);                                            // k-step 0
+    request(s1); request(s0);                                  // k-steps 1, 2 in flight (stage of k-step j: j % 2)
+    __syncthreads();
+    const int nk = kc1 - kc0;
+    // iteration j: MFMAs on LDS buffer j % 2; publish k-step j + 1 into the other buffer; request k-step j + 3 into the freed stage
+    for (int j = 0; j < nk; j += 2) {
+        compute(0); publish(s1, 1); request(s1); __syncthreads();
+        if (j + 1 >= nk) break;
+        compute(1); publish(s0, 0); request(s0); __syncthreads();
+    }
+    // epilogue.  D layout of a 16x16 tile: column = lane & 15, row = 4 * (lane >> 4) + i
+    if (slab) {
+        float* sl = slab + (long long)blockIdx.z * M * N;
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const long long mo = (long long)blockIdx.x * CT_BM + wm * 32 + m * 16 + kg * 4 + i;
+                if (mo >= M) continue;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int n = (nt0 + wn * 4 + j) * 16 + r;
+                    if (n < N) sl[mo * N + n] = acc[m][j][i];
+                }
+            }
+        return;
+    }
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const long long mo = (long long)blockIdx.x * CT_BM + wm * 32 + m * 16 + kg * 4 + i;
+            if (mo >= M) continue;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int n = (nt0 + wn * 4 + j) * 16 + r;
+                if (n >= N) continue;
+                float v = acc[m][j][i] + (bias ? bias[n] : 0.f);
+                if (accumulate) v += ldf(Y + mo * N + n);
+                stf(Y + mo * N + n, v);
+            }
+        }
+}
+
+// ------------------------------------------------------------------------------------------------
 // k=3 convolution with an LDS-staged halo tile (bf16): the large spatial levels.
 //
 // One workgroup = a 4x8x8 block of output voxels (halo 6x10x10) x up to 64 output channels.  The input
@@ -1486,6 +1621,23 @@ static SplitK splitk_plan(int dtype, int mode, int scatter, long long M, int N, 
     return p;
 }
 
+// LDS-tiled kernel for the small levels: bf16, k3, channel counts that fill its 32-wide k-steps and 128-wide column tiles
+static bool conv_tile_ok(int dtype, int mode, int scatter, long long DHW, int Cin, int N) {
+    return dtype == DYCON_BF16 && mode == DYCON_CONV_K3 && !scatter && Cin % 32 == 0 && N % CT_BN == 0 && Cin >= 64 && DHW < 13824;
+}
+static SplitK conv_tile_plan(long long M, int N, int Cin) {
+    const int nKC = 27 * Cin / 32;
+    const long long wgs = ((M + CT_BM - 1) / CT_BM) * (N / CT_BN);
+    SplitK p{1, nKC};
+    if (wgs >= 384) return p;
+    long long s = 768 / wgs;                                  // 3 of the 4 workgroup slots per CU: ONE round of workgroups, no tail
+    if (s > nKC / 8) s = nKC / 8;                             // at least 8 k-steps per split
+    if (s < 2) return p;
+    p.kc_per_split = (int)((nKC + s - 1) / s);
+    p.splits = (nKC + p.kc_per_split - 1) / p.kc_per_split;
+    return p;
+}
+
 extern "C" int dycon_pack_batch(const dycon_pack_job_t* jobs_dev, int njobs, int blocks_per_job, dycon_stream_t stream) {
     DYCON_REQUIRE(jobs_dev && njobs > 0 && njobs <= 65535 && blocks_per_job > 0, "pack_batch: bad arguments");
     pack_batch_kernel<<<dim3(blocks_per_job, njobs), 256, 0, stream>>>(jobs_dev);
@@ -1519,7 +1671,8 @@ extern "C" size_t dycon_conv_gemm_workspace(int dtype, int mode, int scatter, in
     int Do, Ho, Wo;
     row_grid(mode, Di, Hi, Wi, Do, Ho, Wo);
     const long long M = (long long)B * Do * Ho * Wo;
-    const SplitK sk = splitk_plan(dtype, mode, scatter, M, N, Cin);
+    const SplitK sk = conv_tile_ok(dtype, mode, scatter, (long long)Di * Hi * Wi, Cin, N) ? conv_tile_plan(M, N, Cin)
+                                                                                       : splitk_plan(dtype, mode, scatter, M, N, Cin);
     return sk.splits > 1 ? (size_t)sk.splits * M * N * sizeof(float) : 0;
 }
 
@@ -1568,6 +1721,23 @@ extern "C" int dycon_conv_gemm(const void* x, const void* wfrag, const float* bi
         }
 #undef DYCON_CL
         DYCON_LAUNCH_CHECK();
+        return DYCON_OK;
+    }
+    if (conv_tile_ok(dtype, mode, scatter, (long long)Di * Hi * Wi, Cin, N)) {
+        const long long M = (long long)B * Di * Hi * Wi;
+        const int NT = N / 16, nKC = 27 * Cin / 32;
+        SplitK sk = conv_tile_plan(M, N, Cin);
+        const bool split = sk.splits > 1 && workspace && ws_bytes >= (size_t)sk.splits * M * N * sizeof(float);
+        dim3 grid(cdiv(M, CT_BM), N / CT_BN, split ? sk.splits : 1);
+        conv_k3_tile_kernel<<<grid, 256, 0, stream>>>((const bf16*)x, (const bf16*)wfrag, bias, (bf16*)y, split ? workspace : nullptr, B,
+                                                      Di, Hi, Wi, Cin, N, NT, nKC, sk.kc_per_split, accumulate);
+        DYCON_LAUNCH_CHECK();
+        if (split) {
+            long long blocks = (M * N + 255) / 256;
+            if (blocks > 2048) blocks = 2048;
+            splitk_finish_kernel<bf16><<<(int)blocks, 256, 0, stream>>>(workspace, sk.splits, M * N, N, bias, (bf16*)y, accumulate);
+            DYCON_LAUNCH_CHECK();
+        }
         return DYCON_OK;
     }
     // split-K only when the caller provides the slab workspace (NULL -> single pass, same result up to fp32 summation order)

@@ -66,6 +66,8 @@ CONV_CASES = [
     ("k3", 1, 16, (24, 24, 24)), ("k3", 16, 16, (24, 28, 22)), ("k3", 16, 32, (24, 24, 24)), ("k3", 32, 16, (24, 24, 24)),
     ("k3", 32, 32, (26, 24, 24)), ("k3", 64, 64, (24, 24, 24)), ("k3", 16, 64, (24, 24, 24)), ("k3", 64, 128, (24, 24, 24)),
     ("k3", 32, 1 * 16, (20, 28, 25)),
+    # small levels, >= 128 output channels (bf16): LDS-tiled split-K GEMM kernel, ragged row blocks
+    ("k3", 64, 128, (4, 4, 6)), ("k3", 128, 128, (6, 6, 6)), ("k3", 128, 256, (3, 5, 4)), ("k3", 256, 256, (6, 6, 6)),
     # U-Net decoder widths on the LDS kernel: 48 input channels (chunk-major packing), 48 / 96 output channels (3 n-tiles)
     ("k3", 48, 16, (24, 24, 24)), ("k3", 96, 32, (24, 24, 24)), ("k3", 16, 48, (24, 24, 24)), ("k3", 32, 96, (24, 24, 24)),
 ]
