@@ -146,7 +146,13 @@ def conv_gemm(x, wfrag, bias, mode, N, Cout, scatter=False, out=None, accumulate
     nws = query("dycon_conv_gemm_workspace", dt(x), mode, int(scatter), B, D, H, W, Cin, N)
     ws = _ws(nws, x) if nws else None
     lds_path = mode == CONV_K3 and not scatter and conv_uses_lds(x, Cin, Cout)
-    rname = "conv_k3_lds" if lds_path else ("conv_gemm_splitk" if nws else "conv_gemm")
+    if lds_path:      # the persistent kernels of the 16-channel level, or the generic LDS-halo kernel
+        rname = "conv_k3_p16" if (Cin, Cout) == (16, 16) else ("conv_k3_c1" if Cin == 1 else "conv_k3_lds")
+    elif (mode == CONV_K3 and not scatter and x.dtype == torch.bfloat16 and Cin % 32 == 0 and Cin >= 64 and N % 128 == 0
+          and D * H * W < 13824):
+        rname = "conv_k3_tile"
+    else:
+        rname = "conv_gemm_splitk" if nws else "conv_gemm"
     with _Region(rname, (x.numel() + out.numel() * (2 if accumulate else 1)) * _es(x) + taps * Cin * N * _es(x),
                  2 * rows * taps * Cin * N):
         call("dycon_conv_gemm", _p(x), _p(wfrag), _p(bias), _p(out), dt(x), mode, int(scatter), int(accumulate),

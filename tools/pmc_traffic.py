@@ -1,0 +1,50 @@
+"""Turn the two counter passes of tools/pmc_traffic.sh into profiles/<name>.json: HBM bytes per launch for every kernel and
+for the kernel families bench.py reports ("regions").  Corrections as MI355X_MICROARCH.md (HBM section) prescribes for gfx950:
+bytes = 2 * FETCH_SIZE * 1024 (FETCH_SIZE tallies 128-B requests at 64 B; unit KiB) + WRITE_SIZE * 1024.
+usage: pmc_traffic.py <tag> <out.json>"""
+import collections
+import csv
+import json
+import sys
+
+tag, out = sys.argv[1], sys.argv[2]
+
+# kernel-name substring -> bench.py region (ops._Region names)
+REGIONS = [("conv_k3_p16_kernel", "conv_k3_p16"), ("conv_k3_c1_kernel", "conv_k3_c1"), ("conv_k3_lds_kernel", "conv_k3_lds"),
+           ("conv_k3_tile_kernel", "conv_k3_tile"), ("wgrad_k3_bf16_kernel", "wgrad_k3_bf16"), ("wgrad_k2s2_bf16_kernel", "conv_wgrad"),
+           ("conv_wgrad_kernel", "conv_wgrad"), ("conv_gemm_kernel", "conv_gemm"), ("norm_apply_kernel", "norm_fwd"),
+           ("norm_partial_kernel<__hip_bfloat16, 0>", "norm_fwd"), ("norm_fused_fwd_kernel", "norm_fwd"),
+           ("norm_partial_kernel<__hip_bfloat16, 1>", "norm_bwd"), ("norm_bwd_apply_kernel", "norm_bwd"), ("norm_fused_bwd_kernel", "norm_bwd")]
+
+
+def load(kind):
+    rows = list(csv.DictReader(open(f"gpurun_out/pmc_{tag}_{kind}/run_counter_collection.csv")))
+    per = collections.defaultdict(lambda: collections.defaultdict(float))      # kernel -> dispatch -> value
+    for r in rows:
+        per[r["Kernel_Name"]][r["Dispatch_Id"]] += float(r["Counter_Value"])
+    return per
+
+
+fetch, write = load("fetch"), load("write")
+kern = {}
+for name in sorted(set(fetch) | set(write)):
+    f = list(fetch.get(name, {}).values())
+    w = list(write.get(name, {}).values())
+    short = name.split("(")[0]
+    kern[short] = {"launches_counted": max(len(f), len(w)),
+                   "fetch_bytes_per_launch": 2 * 1024 * sum(f) / max(len(f), 1),
+                   "write_bytes_per_launch": 1024 * sum(w) / max(len(w), 1)}
+reg = collections.defaultdict(lambda: [0, 0.0])
+for short, v in kern.items():
+    for pat, region in REGIONS:
+        if pat in short:
+            reg[region][0] += v["launches_counted"]
+            reg[region][1] += v["launches_counted"] * (v["fetch_bytes_per_launch"] + v["write_bytes_per_launch"])
+            break
+doc = {"method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes over `bench.py --steps 2 --warmup 1` (tools/pmc_traffic.sh); "
+                 "bytes = 2*FETCH_SIZE*1024 (gfx950 half-count correction, MI355X_MICROARCH.md HBM section) + WRITE_SIZE*1024; "
+                 "the finalize / finish launches of a region are not attributed to it",
+       "per_region": {k: {"launches_counted": v[0], "hbm_bytes_per_launch": v[1] / max(v[0], 1)} for k, v in sorted(reg.items())},
+       "per_kernel": kern}
+json.dump(doc, open(out, "w"), indent=1)
+print(json.dumps(doc["per_region"], indent=1))
