@@ -65,6 +65,9 @@ SIGNATURES = {
     "dycon_sumsq": (I, [P, L, P, P]),
     "dycon_sgd_ema": (I, [P, P, P, P, L, L, P, F, F, F, F, F, F, P, P]),
     "dycon_nonfinite_flag": (I, [P, P, P]),
+    "dycon_sw_accumulate": (I, [P, I, I, I, I, P, P, P, I, I, I, P]),
+    "dycon_sw_finalize": (I, [P, P, L, F, P, P, P]),
+    "dycon_binary_overlap": (I, [P, P, I, L, P, P]),
 }
 
 

@@ -1,0 +1,144 @@
+"""Sliding-window evaluation with the reference's names and argument meaning (code/utils/test_3d_patch.py).
+
+    test_single_case(model, image, stride_xy, stride_z, patch_size, num_classes=1)   :293-351
+    calculate_metric_percase(pred, gt) -> (dice, jaccard, hd95, asd)                 :496-508
+    test_all_case(model, cases, ...)                                                 :251-291
+
+The windows run through the HIP network in batches; score / count maps, the final threshold and the overlap counts behind Dice
+and Jaccard stay on the MI355X (csrc/eval.hip).  HD95 / ASD are surface-distance metrics of medpy (absent here, not vendored by
+the reference): they are restated on scipy.ndimage on the host ("parity unpinned", see oracle/evaluate.py) -- they are
+per-case diagnostics off the hot path.  The reference reads h5 files (h5py is not available in this image): `test_all_case`
+takes (image, label) arrays, or h5 paths when h5py can be imported.
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+import torch
+
+from .. import _lib, ops
+
+
+def _windows(shape, patch_size, stride_xy, stride_z):
+    ww, hh, dd = shape
+    sx = math.ceil((ww - patch_size[0]) / stride_xy) + 1      # :319-321
+    sy = math.ceil((hh - patch_size[1]) / stride_xy) + 1
+    sz = math.ceil((dd - patch_size[2]) / stride_z) + 1
+    out = []
+    for x in range(sx):
+        xs = min(stride_xy * x, ww - patch_size[0])
+        for y in range(sy):
+            ys = min(stride_xy * y, hh - patch_size[1])
+            for z in range(sz):
+                out.append((xs, ys, min(stride_z * z, dd - patch_size[2])))
+    return out
+
+
+def test_single_case(model, image, stride_xy, stride_z, patch_size, num_classes=1, batch_size=4, device=None):
+    """image: (w, h, d) numpy array or tensor.  Returns (label_map int64 (w,h,d), score_map float32 (num_classes,w,h,d)) as numpy,
+    like the reference; the class-1 probability fills every channel of score_map (the reference's broadcast, :338-339).
+
+    ``batch_size`` windows go through the network per launch sequence (the reference runs them one by one)."""
+    dev = torch.device(device) if device is not None else next(model.parameters()).device
+    if dev.type != "cuda":
+        raise RuntimeError("test_single_case runs on the MI355X only: move the model to 'cuda'")
+    img = torch.as_tensor(np.asarray(image), dtype=torch.float32)
+    w, h, d = img.shape
+    pads = []
+    for size, p in zip((w, h, d), patch_size):                 # :297-316: centre-pad volumes smaller than the window
+        pad = max(p - size, 0)
+        pads.append((pad // 2, pad - pad // 2))
+    add_pad = any(lo or hi for lo, hi in pads)
+    vol = img.to(dev)
+    if add_pad:
+        vol = torch.nn.functional.pad(vol, (pads[2][0], pads[2][1], pads[1][0], pads[1][1], pads[0][0], pads[0][1]))
+    vol = vol.contiguous()
+    ww, hh, dd = vol.shape
+    wins = _windows((ww, hh, dd), patch_size, stride_xy, stride_z)
+    score = torch.zeros((ww, hh, dd), dtype=torch.float32, device=dev)
+    cnt = torch.zeros_like(score)
+    p0, p1, p2 = patch_size
+    stream = lambda: torch.cuda.current_stream().cuda_stream   # noqa: E731
+    was_training = model.training
+    model.eval()
+    try:
+        with torch.no_grad():
+            for i in range(0, len(wins), batch_size):
+                chunk = wins[i:i + batch_size]
+                patches = torch.stack([vol[x:x + p0, y:y + p1, z:z + p2] for x, y, z in chunk]).unsqueeze(1).contiguous()
+                logits = model(patches)[1]                                        # (nb, 2, p0, p1, p2), channels-last-3D view
+                lg = logits.permute(0, 2, 3, 4, 1).contiguous().float()          # NDHWC (free for the HIP nets' outputs)
+                org = torch.tensor(chunk, dtype=torch.int32).to(dev)
+                _lib.call("dycon_sw_accumulate", lg.data_ptr(), len(chunk), p0, p1, p2, org.data_ptr(), score.data_ptr(),
+                          cnt.data_ptr(), ww, hh, dd, stream())
+    finally:
+        model.train(was_training)
+    label = torch.empty((ww, hh, dd), dtype=torch.uint8, device=dev)
+    prob = torch.empty_like(score)
+    _lib.call("dycon_sw_finalize", score.data_ptr(), cnt.data_ptr(), score.numel(), 0.5, label.data_ptr(), prob.data_ptr(), stream())
+    if add_pad:
+        sl = tuple(slice(lo, lo + n) for (lo, _), n in zip(pads, (w, h, d)))
+        label, prob = label[sl], prob[sl]
+    label_map = label.cpu().numpy().astype(np.int64)
+    score_map = np.broadcast_to(prob.cpu().numpy()[None], (num_classes,) + label_map.shape).copy()
+    return label_map, score_map
+
+
+def overlap_counts(pred, gt):
+    """(|pred|, |gt|, |pred & gt|) on the device.  pred / gt: CUDA tensors (uint8 / int64) or numpy arrays."""
+    dev = pred.device if torch.is_tensor(pred) and pred.is_cuda else torch.device("cuda:0")
+    p = torch.as_tensor(np.asarray(pred) if not torch.is_tensor(pred) else pred).to(dev).ne(0).to(torch.uint8).contiguous()
+    g = torch.as_tensor(np.asarray(gt) if not torch.is_tensor(gt) else gt).to(dev)
+    g = (g if g.dtype in (torch.uint8, torch.int64) else g.ne(0).to(torch.uint8)).contiguous()
+    out = torch.zeros(3, dtype=torch.int64, device=dev)
+    _lib.call("dycon_binary_overlap", p.data_ptr(), g.data_ptr(), g.element_size(), p.numel(), out.data_ptr(),
+              torch.cuda.current_stream().cuda_stream)
+    return tuple(int(v) for v in out.tolist())
+
+
+def _surface_distances(result, reference, voxelspacing=None, connectivity=1):
+    from scipy import ndimage
+    result, reference = np.atleast_1d(result.astype(bool)), np.atleast_1d(reference.astype(bool))
+    footprint = ndimage.generate_binary_structure(result.ndim, connectivity)
+    if 0 == np.count_nonzero(result):
+        raise RuntimeError("The first supplied array does not contain any binary object.")
+    if 0 == np.count_nonzero(reference):
+        raise RuntimeError("The second supplied array does not contain any binary object.")
+    result_border = result ^ ndimage.binary_erosion(result, structure=footprint, iterations=1)
+    reference_border = reference ^ ndimage.binary_erosion(reference, structure=footprint, iterations=1)
+    return ndimage.distance_transform_edt(~reference_border, sampling=voxelspacing)[result_border]
+
+
+def calculate_metric_percase(pred, gt):
+    """(dice, jaccard, hd95, asd) of one case, medpy.metric.binary semantics (code/utils/test_3d_patch.py:496-508)."""
+    n_p, n_g, n_i = overlap_counts(pred, gt)
+    dice = 2.0 * n_i / float(n_p + n_g) if n_p + n_g else 0.0
+    jc = float(n_i) / float(n_p + n_g - n_i)               # ZeroDivisionError for two empty masks, as medpy
+    if n_g == 0:
+        return dice, jc, 0.0, 0.0
+    p = np.asarray(pred.cpu() if torch.is_tensor(pred) else pred) != 0
+    g = np.asarray(gt.cpu() if torch.is_tensor(gt) else gt) != 0
+    hd1, hd2 = _surface_distances(p, g), _surface_distances(g, p)
+    return dice, jc, float(np.percentile(np.hstack((hd1, hd2)), 95)), float(hd1.mean())
+
+
+def test_all_case(model, cases, num_classes, patch_size=(96, 96, 64), stride_xy=16, stride_z=4, batch_size=4, metric_detail=0):
+    """cases: iterable of (image, label) arrays, or of h5 paths with 'image' / 'label' datasets (needs h5py).
+    Returns the mean (dice, jaccard, hd95, asd) over the cases (code/utils/test_3d_patch.py:251-291)."""
+    total = np.zeros(4)
+    n = 0
+    for case in cases:
+        if isinstance(case, (str, bytes)):
+            import h5py   # not available in this image; present where the datasets are
+            with h5py.File(case, "r") as f:
+                image, label = f["image"][:], f["label"][:]
+        else:
+            image, label = case
+        pred, _ = test_single_case(model, image, stride_xy, stride_z, patch_size, num_classes=num_classes, batch_size=batch_size)
+        m = (0.0, 0.0, 0.0, 0.0) if pred.sum() == 0 else calculate_metric_percase(pred, np.asarray(label))
+        if metric_detail:
+            print("%02d,\t%.5f, %.5f, %.5f, %.5f" % ((n,) + tuple(m)))
+        total += np.asarray(m)
+        n += 1
+    return total / max(n, 1)

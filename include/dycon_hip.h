@@ -244,6 +244,21 @@ int dycon_set_scalars(float* dst, int n, float v0, float v1, float v2, float v3,
 /* flag[0] = !isfinite(x[0]) */
 int dycon_nonfinite_flag(const float* x, int* flag, dycon_stream_t stream);
 
+/* ---------------------------------------------------------------- sliding-window evaluation (code/utils/test_3d_patch.py:293-351)
+ * score / cnt: fp32 maps of the (padded) volume D0 x D1 x D2, zeroed by the caller.  After a batch of n_patches <= 64 windows
+ * went through the network, add for every voxel the class-1 softmax of each window covering it (logits: (n_patches, p0, p1, p2, 2)
+ * fp32; origins_dev: n_patches x 3 ints, window corner in the volume) and the window count.  Voxel-centric, fixed window order:
+ * deterministic although windows overlap. */
+int dycon_sw_accumulate(const float* logits, int n_patches, int p0, int p1, int p2, const int* origins_dev,
+                        float* score, float* cnt, int D0, int D1, int D2, dycon_stream_t stream);
+/* prob = score / cnt (may be NULL), label = prob > thresh   (:344-345) */
+int dycon_sw_finalize(const float* score, const float* cnt, long long n, float thresh, uint8_t* label,
+                      float* prob, dycon_stream_t stream);
+/* out3 (device, caller zeroes) += { |pred|, |gt|, |pred & gt| }: the counts behind medpy.metric.binary.dc / jc
+ * (test_3d_patch.py:496-508).  gt: uint8 (gt_bytes 1) or int64 (8), non-zero = foreground. */
+int dycon_binary_overlap(const uint8_t* pred, const void* gt, int gt_bytes, long long n,
+                         unsigned long long* out3, dycon_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,55 @@
+"""CPU checks of the evaluator oracle (oracle/evaluate.py) and of the window enumeration the HIP evaluator shares with it."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import evaluate as OE
+
+
+def test_metrics_known_answers():
+    shape = (30, 30, 30)
+    a = np.zeros(shape, bool); a[10:20, 10:20, 10:20] = True
+    b = np.zeros(shape, bool); b[13:23, 10:20, 10:20] = True
+    d, j, hd, asd = OE.calculate_metric_percase(a, b)
+    assert d == pytest.approx(0.7) and j == pytest.approx(7 / 13)
+    assert hd == pytest.approx(3.0) and 0.0 < asd < 3.0
+    assert OE.calculate_metric_percase(a, a) == (1.0, 1.0, 0.0, 0.0)
+    assert OE.calculate_metric_percase(a, np.zeros(shape, bool))[2:] == (0.0, 0.0)      # test_3d_patch.py:500-503
+    with pytest.raises(ZeroDivisionError):
+        OE.jc(np.zeros(shape, bool), np.zeros(shape, bool))                            # medpy raises for two empty masks
+
+
+@pytest.mark.parametrize("shape,patch,sxy,sz", [((20, 24, 18), (16, 16, 16), 8, 4), ((10, 40, 16), (16, 16, 16), 16, 16)])
+def test_single_case_windows_and_padding(shape, patch, sxy, sz):
+    """A 'network' whose class-1 logit is the patch itself: score = mean over the covering windows of sigmoid(2x) = sigmoid(2x)
+    wherever all windows see the same voxel value (they do: windows are crops) -- checks coverage, clamped last windows, padding."""
+    rng = np.random.default_rng(1)
+    image = rng.standard_normal(shape).astype(np.float32)
+
+    def net(t):
+        return torch.cat([-t, t], 1)
+
+    label, score = OE.test_single_case(net, image, sxy, sz, patch, num_classes=2)
+    assert label.shape == shape and score.shape == (2,) + shape
+    expect = 1.0 / (1.0 + np.exp(-2.0 * image))
+    np.testing.assert_allclose(score[0], expect, rtol=1e-5, atol=1e-6)
+    np.testing.assert_array_equal(score[0], score[1])                                  # the reference's broadcast (:338-339)
+    np.testing.assert_array_equal(label, (expect > 0.5).astype(int))
+
+
+def test_window_enumeration_matches_host_mirror():
+    """dycon_paper_replication_amd.utils.test_3d_patch._windows (host logic of the HIP path) == the oracle's loops."""
+    import importlib
+    import math
+    t3 = importlib.import_module("dycon_paper_replication_amd.utils.test_3d_patch")
+    for shape, patch, sxy, sz in [((40, 48, 36), (32, 32, 32), 16, 8), ((96, 96, 64), (96, 96, 64), 16, 4), ((155, 100, 97), (96, 96, 64), 16, 4)]:
+        wins = t3._windows(shape, patch, sxy, sz)
+        n = 1
+        for s, p, st in zip(shape, patch, (sxy, sxy, sz)):
+            n *= math.ceil((s - p) / st) + 1
+        assert len(wins) == n
+        cover = np.zeros(shape, np.int32)
+        for x, y, z in wins:
+            assert x + patch[0] <= shape[0] and y + patch[1] <= shape[1] and z + patch[2] <= shape[2]
+            cover[x:x + patch[0], y:y + patch[1], z:z + patch[2]] += 1
+        assert cover.min() >= 1
