@@ -295,10 +295,37 @@ class DyconTrainer:
         return {"student": self.state_dict(), "teacher": self.teacher_state_dict(), "momentum": self.flat_m.clone(),
                 "iter_num": self.iter_num, "lr": self.lr, "skipped_steps": self.skipped_steps}
 
+    def save_checkpoint(self, path, resume_sidecar=True):
+        """`torch.save(student.state_dict(), path)` exactly as the reference does (train_DyCON_BraTS19.py:411-430: student only,
+        reference keys -- loadable by code/test_BraTS19.py:62-63), plus `<path>.resume` with everything the reference drops
+        (teacher, momentum, iteration counter, LR): SURVEY section 8f-3."""
+        torch.save(OrderedDict((k, v.cpu()) for k, v in self.state_dict().items()), path)
+        if resume_sidecar:
+            st = self.full_state()
+            st["student"] = None                                 # lives in `path`
+            st["teacher"] = OrderedDict((k, v.cpu()) for k, v in st["teacher"].items())
+            st["momentum"] = st["momentum"].cpu()
+            torch.save(st, str(path) + ".resume")
+
+    def load_checkpoint(self, path):
+        """Load a reference-format student checkpoint; with a `.resume` sidecar next to it, continue the run bit for bit."""
+        import os
+        student = torch.load(path, map_location="cpu", weights_only=True)
+        side = str(path) + ".resume"
+        if os.path.exists(side):
+            st = torch.load(side, map_location="cpu", weights_only=True)
+            st["student"] = student
+            self.load_full_state(st)
+        else:                                                   # evaluation-style load: weights only, teacher = student (EMA restarts)
+            self.model.load_state_dict(student)
+            for e in (self.s_eng, self.t_eng):
+                e.params_changed()
+            self.model.params_changed()
+
     def load_full_state(self, st):
         self.model.load_state_dict(st["student"])
         self.ema_model.load_state_dict(st["teacher"])
-        self.flat_m.copy_(st["momentum"])
+        self.flat_m.copy_(st["momentum"].to(self.device))
         self.iter_num, self.lr, self.skipped_steps = st["iter_num"], st["lr"], st["skipped_steps"]
         for e in (self.s_eng, self.t_eng):
             e.params_changed()

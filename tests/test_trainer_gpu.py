@@ -109,3 +109,31 @@ def test_philox_step_runs_and_is_reproducible():
         res.append((float(o["loss"]), tr.flat_p.clone()))
     assert np.isfinite(res[0][0])
     assert res[0][0] == pytest.approx(res[1][0], rel=1e-5)
+
+
+def test_checkpoint_resume_continues_the_run(tmp_path):
+    """save (reference-format student .pth + resume sidecar) after 2 steps, load into a fresh trainer, run 2 more:
+    the same as 4 uninterrupted steps (on-device Philox streams are functions of the iteration counter); the .pth
+    alone loads into the oracle's functional net (reference key contract)."""
+    from dycon_paper_replication_amd.synthetic import make_batch
+    vol, lab, _ = make_batch(11, 2, (32, 32, 32))
+    vol, lab = vol.cuda(), lab.cuda()
+    cfg = TrainConfig(model="vnet", labeled_bs=1, batch_size=2, dtype=torch.bfloat16, seed=5)
+    a = DyconTrainer(cfg, "cuda:0")
+    for _ in range(2):
+        a.step(vol, lab)
+    path = tmp_path / "iter_2.pth"
+    a.save_checkpoint(path)
+    for _ in range(2):
+        a.step(vol, lab)
+    b = DyconTrainer(cfg, "cuda:0")
+    b.load_checkpoint(path)
+    assert b.iter_num == 2
+    for _ in range(2):
+        out = b.step(vol, lab)
+    # the kernels are deterministic up to the double-precision atomic loss sums (their last bits can differ between runs)
+    for x, y in ((a.flat_p, b.flat_p), (a.flat_t, b.flat_t), (a.flat_m, b.flat_m)):
+        assert float((x - y).abs().max()) <= 1e-6 * float(x.abs().max())
+    assert np.isfinite(float(out["loss"]))
+    sd = torch.load(path, map_location="cpu", weights_only=True)
+    assert list(sd) == list(a.state_dict())
