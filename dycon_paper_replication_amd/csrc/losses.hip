@@ -189,23 +189,28 @@ __global__ __launch_bounds__(256) void l2norm_bwd_kernel(const T* __restrict__ Y
     for (int c = lane; c < C; c += 64) stf(GX + row * C + c, (ldf(GY + row * C + c) - ldf(Y + row * C + c) * proj) / nrm);
 }
 
-__global__ void mask_pool_kernel(const void* __restrict__ labels, int label_bytes, float* __restrict__ mask, int B, int D, int H,
-                                 int W, int kd, int kh, int kw) {
+// one wave per pooled cell: the 64 lanes walk the cell's kd*kh*kw voxels (x fastest: coalesced) and add up with shuffles --
+// a thread per cell would read its 512 voxels serially with a 512-byte stride between neighbouring threads
+__global__ __launch_bounds__(256) void mask_pool_kernel(const void* __restrict__ labels, int label_bytes, float* __restrict__ mask, int B,
+                                                        int D, int H, int W, int kd, int kh, int kw) {
     const int Do = D / kd, Ho = H / kh, Wo = W / kw;
     const long long total = (long long)B * Do * Ho * Wo;
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long i = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (i >= total) return;
+    const int lane = threadIdx.x & 63;
     long long q = i;
     const int x = (int)(q % Wo); q /= Wo;
     const int y = (int)(q % Ho); q /= Ho;
     const int z = (int)(q % Do);
     const int b = (int)(q / Do);
+    const int cell = kd * kh * kw;
     float s = 0.f;
-    for (int dz = 0; dz < kd; ++dz)
-        for (int dy = 0; dy < kh; ++dy)
-            for (int dx = 0; dx < kw; ++dx)
-                s += (float)load_label(labels, label_bytes, (((long long)b * D + z * kd + dz) * H + y * kh + dy) * W + x * kw + dx);
-    mask[i] = (s / (float)(kd * kh * kw)) > 0.5f ? 1.f : 0.f;
+    for (int e = lane; e < cell; e += 64) {
+        const int dx = e % kw, dy = (e / kw) % kh, dz = e / (kw * kh);
+        s += (float)load_label(labels, label_bytes, (((long long)b * D + z * kd + dz) * H + y * kh + dy) * W + x * kw + dx);
+    }
+    s = wave_sum(s);      // integer-valued partial sums: exact in any order
+    if (lane == 0) mask[i] = (s / (float)cell) > 0.5f ? 1.f : 0.f;
 }
 
 // =================================================================================================
@@ -686,7 +691,7 @@ extern "C" int dycon_mask_pool(const void* labels, int label_bytes, float* mask,
     DYCON_REQUIRE(labels && mask && B > 0 && kd > 0 && kh > 0 && kw > 0 && D >= kd && H >= kh && W >= kw, "mask_pool: bad arguments");
     DYCON_REQUIRE(label_bytes == 1 || label_bytes == 8, "mask_pool: labels must be uint8 or int64");
     const long long total = (long long)B * (D / kd) * (H / kh) * (W / kw);
-    mask_pool_kernel<<<cdiv(total, 256), 256, 0, stream>>>(labels, label_bytes, mask, B, D, H, W, kd, kh, kw);
+    mask_pool_kernel<<<cdiv(total, 4), 256, 0, stream>>>(labels, label_bytes, mask, B, D, H, W, kd, kh, kw);
     DYCON_LAUNCH_CHECK();
     return DYCON_OK;
 }
