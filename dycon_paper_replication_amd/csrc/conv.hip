@@ -797,11 +797,12 @@ __global__ __launch_bounds__(256, P16_WGS) void conv_k3_p16_kernel(const bf16* _
     load_halo(g0, s0);
     store_halo(g0, s0);                                      // (the wait for s0 also retires the weight loads)
     gcur = g0;
-    geometry(tile + t_stride, g1);
-    load_halo(g1, s1);
+    if (DEPTH >= 2) { geometry(tile + t_stride, g1); load_halo(g1, s1); }
     if (DEPTH == 3) { geometry(tile + 2 * t_stride, g2); load_halo(g2, s2); }
     __syncthreads();
-    if (DEPTH == 2) {
+    if (DEPTH == 1) {
+        for (; tile < t_end; tile += t_stride) one_tile(tile, gcur, g0, s0, g0, s0);   // load j+1 at the top, write it at the end
+    } else if (DEPTH == 2) {
         for (; tile < t_end; tile += 2 * t_stride) {         // tile j: loads j+2 into set j%2 (free since j was written), writes j+1
             one_tile(tile, gcur, g0, s0, g1, s1);
             one_tile(tile + t_stride, gcur, g1, s1, g0, s0);

@@ -143,6 +143,7 @@ class Engine:
         self._packed = {}
         self._jobs, self._jobs_dev, self._packed_gen = [], None, -1
         self.on_param_grads = None   # optional callback(name): called in backward once a layer's parameter gradients are enqueued
+        self.wgrad_stream = None     # optional side stream for the weight-gradient launches of the backward (set by the trainer)
         self.tape = []
         self.G = {}
 
@@ -244,8 +245,7 @@ class Engine:
             y = ops.conv_gemm(x, wf, b, mode, Cout, Cout)
 
         if self.recording:
-            def bwd():
-                gy = self._take(y)
+            def wgrad(gy):
                 gw, gb = self.g[name + ".weight"], self.g[name + ".bias"]
                 if kind == "deconv":   # dW[ci][co][t] = sum_m x[m,ci] * gy[2m+t,co]   (roles of x and gy swapped)
                     ops.colsum(gy, gb)
@@ -254,6 +254,21 @@ class Engine:
                     ops.conv_wgrad(x, gy, gw, mode, 1 if T > 1 else 0, T, Cin * T, dbias=gb)
                 if self.on_param_grads is not None:
                     self.on_param_grads(name + ".weight")      # this layer's gradients are enqueued (DDP bucket trigger)
+
+            def bwd():
+                gy = self._take(y)
+                if self.wgrad_stream is not None:
+                    # The weight gradient only feeds the optimiser; the data gradient is the critical chain.  Enqueue the former on a
+                    # second HIP stream (behind an event that marks gy ready) so the small-level wgrad / reduce launches fill the
+                    # CUs the latency-bound dgrad / norm-backward kernels leave idle.  backward() joins the streams at the end.
+                    ev = torch.cuda.Event()
+                    ev.record()
+                    with torch.cuda.stream(self.wgrad_stream):
+                        self.wgrad_stream.wait_event(ev)
+                        wgrad(gy)
+                    gy.record_stream(self.wgrad_stream)
+                else:
+                    wgrad(gy)
                 if not need_gx:
                     return
                 cur = self.G.get(id(x))
@@ -482,4 +497,6 @@ class Engine:
         self.G[id(feats)] = g_feats
         for fn in reversed(self.tape):
             fn()
+        if self.wgrad_stream is not None:
+            torch.cuda.current_stream().wait_stream(self.wgrad_stream)   # all parameter gradients are complete behind this point
         self.tape, self.G = [], {}

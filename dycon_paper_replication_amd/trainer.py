@@ -66,6 +66,7 @@ class TrainConfig:
     strict_nan_check: bool = True       # read the NaN/Inf flag every step, as the reference does
     global_batch_losses: bool = True    # DDP: all-reduce the Dice / FeCL-cross sums (exact global-batch semantics)
     overlap_teacher: bool = True        # teacher forward on a second HIP stream, concurrent with the student forward
+    overlap_wgrad: bool = True          # weight-gradient launches of the backward on a second HIP stream (off the dgrad chain)
 
 
 class DyconTrainer:
@@ -136,6 +137,8 @@ class DyconTrainer:
         self.flag_host = torch.zeros(1, dtype=torch.int32).pin_memory()
         self.flag_evt = torch.cuda.Event()
         self.side = torch.cuda.Stream(device=self.device)
+        if cfg.overlap_wgrad:
+            self.s_eng.wgrad_stream = torch.cuda.Stream(device=self.device)
         # DDP gradient buckets: contiguous arena ranges cut at parameter boundaries.  The backward writes gradients in reverse
         # registration order, so a bucket is complete when its FIRST parameter's gradient has been enqueued; its all-reduce is
         # issued right then and overlaps the rest of the backward (xGMI ring: 4 x ~10 MB instead of one 39 MB transfer at the end).
@@ -158,6 +161,11 @@ class DyconTrainer:
     def _on_param_grads(self, name):
         rng = self._bucket_of.get(name)
         if rng is not None:
+            cur = torch.cuda.current_stream()
+            if cur != self._main:      # called from the weight-gradient stream: the bucket also holds norm / bias gradients that
+                ev = torch.cuda.Event()    # the main stream wrote -- the collective must wait for both streams
+                ev.record(self._main)
+                cur.wait_event(ev)
             self._pending.append(torch.distributed.all_reduce(self.flat_g[rng[0]:rng[1]], group=self.pg, async_op=True))
 
     # ------------------------------------------------------------------ schedules (host scalars)
@@ -201,7 +209,7 @@ class DyconTrainer:
         # The teacher forward (:305-306) is independent of the student forward (:304): it runs on a second HIP stream so the
         # small, launch-latency-bound kernels of the deep levels (6^3, 12^3: 50-100 workgroups on 256 CUs) of the two nets overlap.
         t_train = c.teacher_mode == "train"
-        main = torch.cuda.current_stream()
+        main = self._main = torch.cuda.current_stream()
         if c.overlap_teacher:
             self.side.wait_stream(main)
             with torch.cuda.stream(self.side):
