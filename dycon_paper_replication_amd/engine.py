@@ -144,6 +144,9 @@ class Engine:
         self._jobs, self._jobs_dev, self._packed_gen = [], None, -1
         self.on_param_grads = None   # optional callback(name): called in backward once a layer's parameter gradients are enqueued
         self.wgrad_stream = None     # optional side stream for the weight-gradient launches of the backward (set by the trainer)
+        self.feat_stream = None      # optional stream for the feature branch (projection head forward + backward), see forward()
+        self.Gs = {}
+        self._head_range = (0, 0)
         self.tape = []
         self.G = {}
 
@@ -204,12 +207,39 @@ class Engine:
         self._packed_gen = self.gen
 
     # ---------------------------------------------------------------- gradient bookkeeping
+    # With the feature branch on its own stream (feat_stream) gradients cross streams at the tensor both branches consume
+    # (x5 / center): every entry of G remembers the stream that produced it, and whoever reads or accumulates it from another
+    # stream waits for that stream first (and tells the caching allocator about the second user).
+    def _sync_to(self, key, g):
+        if self.feat_stream is None:
+            return
+        cur = torch.cuda.current_stream()
+        src = self.Gs.get(key)
+        if src is not None and src != cur:
+            cur.wait_stream(src)
+            g.record_stream(cur)
+
     def _take(self, t):
-        return self.G.pop(id(t))
+        g = self.G.pop(id(t))
+        self._sync_to(id(t), g)
+        self.Gs.pop(id(t), None)
+        return g
+
+    def _peek(self, t):
+        """the gradient accumulated so far for t (or None), safe to read / accumulate into on the current stream"""
+        g = self.G.get(id(t))
+        if g is not None:
+            self._sync_to(id(t), g)
+        return g
+
+    def _put(self, t, g):
+        self.G[id(t)] = g
+        if self.feat_stream is not None:
+            self.Gs[id(t)] = torch.cuda.current_stream()
 
     def _give(self, t, g):
-        cur = self.G.get(id(t))
-        self.G[id(t)] = g if cur is None else ops.add(cur, g)
+        cur = self._peek(t)
+        self._put(t, g if cur is None else ops.add(cur, g))
 
     # ---------------------------------------------------------------- conv layers
     def _conv(self, name, x, kind, need_gx=True, out_dtype=None):
@@ -271,7 +301,7 @@ class Engine:
                     wgrad(gy)
                 if not need_gx:
                     return
-                cur = self.G.get(id(x))
+                cur = self._peek(x)
                 if skinny:             # 1x1 head: gx[m,ci] = sum_co gy[m,co] W[co][ci]
                     wd = self._pk((name, "tcn_d"), "tcn", w, 1, Cout, Cin, Cin, 0, Cin, 0, 1)
                     gx = ops.conv_direct(gy, wd, None, CONV_1X1, Cin, x.dtype, out=cur, accumulate=cur is not None)
@@ -290,7 +320,7 @@ class Engine:
                 else:                  # 1x1
                     wd = self._pk((name, "d"), "frag", w, 1, Cout, Cin, Cin, 0, Cin, 0, 1)
                     gx = ops.conv_gemm(gy, wd, None, CONV_1X1, Cin, Cin, out=cur, accumulate=cur is not None)
-                self.G[id(x)] = gx
+                self._put(x, gx)
             self.tape.append(bwd)
         return y
 
@@ -384,6 +414,27 @@ class Engine:
         out = self._conv("projection.3", hdn, "1x1")
         return self._norm("projection.4", out, "bn", relu=False, training=training)
 
+    def _mark_ready(self):
+        if self.feat_stream is None:
+            return None
+        ev = torch.cuda.Event()
+        ev.record()
+        return ev
+
+    def _head_branch(self, center, ready, training):
+        """The projection head depends on the bottleneck only: with feat_stream set it is enqueued there, behind the event
+        recorded when the bottleneck was complete, and overlaps the decoder; its tape entries are replayed on that stream too."""
+        h0 = len(self.tape)
+        if self.feat_stream is None:
+            feats = self._head(center, training)
+        else:
+            with torch.cuda.stream(self.feat_stream):
+                self.feat_stream.wait_event(ready)
+                feats = self._head(center, training)
+            center.record_stream(self.feat_stream)
+        self._head_range = (h0, len(self.tape))
+        return feats
+
     # ---------------------------------------------------------------- V-Net
     def _vnet(self, x, training):
         nk = "gn" if self.normalization == "groupnorm" else "in"
@@ -408,13 +459,14 @@ class Engine:
         x3 = block("block_three", down("block_two_dw", x2), 3)
         x4 = block("block_four", down("block_three_dw", x3), 3)
         x5 = block("block_five", down("block_four_dw", x4), 3, drop=("drop5", 0))   # + Dropout3d, VNet.py:195-196
+        x5_ready = self._mark_ready()
         u = up("block_five_up", x5, x4)
         u = up("block_six_up", block("block_six", u, 3), x3)
         u = up("block_seven_up", block("block_seven", u, 3), x2)
         u = up("block_eight_up", block("block_eight", u, 2), x1)
         x9 = block("block_nine", u, 1, drop=("drop9", 1))                            # + Dropout3d, VNet.py:225-226
         logits = self._conv("out_conv", x9, "1x1", out_dtype=torch.float32)
-        feats = self._head(x5, training)
+        feats = self._head_branch(x5, x5_ready, training)
         return logits, feats, None
 
     # ---------------------------------------------------------------- U-Net
@@ -452,12 +504,13 @@ class Engine:
         c3 = uconv("conv3", pool(c2))
         c4 = uconv("conv4", pool(c3))
         center = self._drop_elements(uconv("center", pool(c4)), "drop_center", 0.3, 0)
+        center_ready = self._mark_ready()
         u4 = upcat("up_concat4", c4, center)
         u3 = upcat("up_concat3", c3, u4)
         u2 = upcat("up_concat2", c2, u3)
         u1 = self._drop_elements(upcat("up_concat1", c1, u2), "drop_up1", 0.3, 1)
         logits = self._conv("out_conv2", u1, "1x1", out_dtype=torch.float32)
-        feats = self._head(center, training)
+        feats = self._head_branch(center, center_ready, training)
         sdf = None
         if want_sdf:   # tanh(final(up1)) -- returned for API parity, discarded by the training step
             rec, self.recording = self.recording, False
@@ -493,10 +546,22 @@ class Engine:
             g_logits = torch.zeros_like(logits)
         if g_feats is None:
             g_feats = torch.zeros_like(feats)
-        self.G[id(logits)] = g_logits
-        self.G[id(feats)] = g_feats
-        for fn in reversed(self.tape):
-            fn()
+        self.Gs = {}
+        self._put(logits, g_logits)
+        if self.feat_stream is not None:
+            with torch.cuda.stream(self.feat_stream):
+                self._put(feats, g_feats)                    # produced by the caller on the feature stream
+        else:
+            self._put(feats, g_feats)
+        h0, h1 = self._head_range
+        for i in range(len(self.tape) - 1, -1, -1):
+            if self.feat_stream is not None and h0 <= i < h1:
+                with torch.cuda.stream(self.feat_stream):   # feature branch: concurrent with the decoder's backward
+                    self.tape[i]()
+            else:
+                self.tape[i]()
+        if self.feat_stream is not None:
+            torch.cuda.current_stream().wait_stream(self.feat_stream)
         if self.wgrad_stream is not None:
             torch.cuda.current_stream().wait_stream(self.wgrad_stream)   # all parameter gradients are complete behind this point
         self.tape, self.G = [], {}

@@ -16,6 +16,7 @@ semantics of the Dice ratio and of the FeCL cross-branch ratio (SURVEY.md sectio
 """
 from __future__ import annotations
 
+import contextlib
 import math
 from collections import OrderedDict
 from dataclasses import dataclass
@@ -67,6 +68,7 @@ class TrainConfig:
     global_batch_losses: bool = True    # DDP: all-reduce the Dice / FeCL-cross sums (exact global-batch semantics)
     overlap_teacher: bool = True        # teacher forward on a second HIP stream, concurrent with the student forward
     overlap_wgrad: bool = True          # weight-gradient launches of the backward on a second HIP stream (off the dgrad chain)
+    overlap_features: bool = True       # feature branch (projection head, embeddings, FeCL forward + backward) on its own stream
 
 
 class DyconTrainer:
@@ -139,6 +141,10 @@ class DyconTrainer:
         self.side = torch.cuda.Stream(device=self.device)
         if cfg.overlap_wgrad:
             self.s_eng.wgrad_stream = torch.cuda.Stream(device=self.device)
+        # The feature branch -- projection head -> normalised embeddings -> FeCL, forward and backward -- meets the segmentation
+        # branch only at the bottleneck tensor and in the scalar loss: it runs on a third stream, beside the decoder.
+        self.feat = torch.cuda.Stream(device=self.device) if cfg.overlap_features else None
+        self.s_eng.feat_stream = self.feat
         # DDP gradient buckets: contiguous arena ranges cut at parameter boundaries.  The backward writes gradients in reverse
         # registration order, so a bucket is complete when its FIRST parameter's gradient has been enqueued; its all-reduce is
         # issued right then and overlaps the rest of the backward (xGMI ring: 4 x ~10 MB instead of one 39 MB transfer at the end).
@@ -202,7 +208,8 @@ class DyconTrainer:
             t_drop = DropoutSpec("philox", seed=seed, offset=(2 * it + 1) << 42) if c.teacher_mode == "train" else DropoutSpec("off")
 
         self.s_eng.repack()          # all weight packs of the step (student fwd + dgrad, teacher fwd): one launch each
-        self.t_eng.repack()          # (on the main stream, before the side stream forks from it)
+        if not c.overlap_teacher:
+            self.t_eng.repack()
         x = volume.reshape(B, D, H, W, 1) if volume.is_contiguous() else volume.contiguous().reshape(B, D, H, W, 1)
         x_t = ops.add_noise(x, None if noise is None else noise.contiguous(), 0.1, 0.2, seed ^ 0x5DEECE66D, it << 32)  # :301-302
 
@@ -213,6 +220,7 @@ class DyconTrainer:
         if c.overlap_teacher:
             self.side.wait_stream(main)
             with torch.cuda.stream(self.side):
+                self.t_eng.repack()  # the teacher's packs belong to its stream (the EMA update that changed them precedes the fork)
                 t_logits, t_feat, _ = self.t_eng.forward(x_t, training=t_train, record=False, dropout=t_drop, update_bn=t_train)
             x_t.record_stream(self.side)
         s_logits, s_feat, _ = self.s_eng.forward(x, training=True, record=True, dropout=s_drop, update_bn=True)   # :304
@@ -227,13 +235,22 @@ class DyconTrainer:
         world = self.world
         glob = world > 1 and c.global_batch_losses
         sums = ops.seg_losses_fwd(s_logits, t_logits, label, LB, beta)
-        s_emb, s_nrm = ops.l2norm_fwd(s_feat.reshape(B, -1, s_feat.shape[-1]))          # :316-319
-        t_emb, _ = ops.l2norm_fwd(t_feat.reshape(B, -1, t_feat.shape[-1]))              # :321-323
-        k = (D // s_feat.shape[1], H // s_feat.shape[2], W // s_feat.shape[3])
-        mask = ops.mask_pool(label, k)                                                   # :326-330
-        teacher_emb = t_emb if c.use_teacher_loss else None
-        fargs = (s_emb, teacher_emb, mask, None, c.temp, c.gamma, bool(c.use_focal), thr)
-        f_loss, fst = ops.fecl_fwd(*fargs, 1.0)
+        fctx = torch.cuda.stream(self.feat) if self.feat is not None else contextlib.nullcontext()
+        with fctx:
+            if self.feat is not None:                     # teacher features (the student's head was enqueued on self.feat)
+                self.feat.wait_stream(self.side if c.overlap_teacher else main)
+                t_feat.record_stream(self.feat)
+            s_emb, s_nrm = ops.l2norm_fwd(s_feat.reshape(B, -1, s_feat.shape[-1]))          # :316-319
+            t_emb, _ = ops.l2norm_fwd(t_feat.reshape(B, -1, t_feat.shape[-1]))              # :321-323
+            k = (D // s_feat.shape[1], H // s_feat.shape[2], W // s_feat.shape[3])
+            mask = ops.mask_pool(label, k)                                                   # :326-330
+            teacher_emb = t_emb if c.use_teacher_loss else None
+            fargs = (s_emb, teacher_emb, mask, None, c.temp, c.gamma, bool(c.use_focal), thr)
+            f_loss, fst = ops.fecl_fwd(*fargs, 1.0)
+        if self.feat is not None:
+            main.wait_stream(self.feat)                   # the scalar loss (and the DDP exchange below) needs the FeCL sums
+            for t in (t_feat, f_loss, fst.out, mask):
+                t.record_stream(main)
         gw = 1
         if glob:
             # Dice is a ratio of batch-GLOBAL sums (losses.py:11-14) and the FeCL cross branch a global sum over a
@@ -256,9 +273,12 @@ class DyconTrainer:
         ops.set_scalars(self.coef, [c.l_weight, c.l_weight * (1 - dice_kind) * gw, c.l_weight * dice_kind * gw, cw,
                                     c.u_weight, c.u_weight])
         g_logits = ops.seg_losses_bwd(s_logits, t_logits, label, LB, beta, sums, self.coef, cons_kind)
-        g_emb = ops.fecl_bwd(*fargs, float(gw), fst, self.coef[5:6])
-        g_feat = ops.l2norm_bwd(s_emb, s_nrm, g_emb).reshape(s_feat.shape)
-        self.s_eng.backward(g_logits, g_feat)
+        if self.feat is not None:
+            self.feat.wait_stream(main)                   # coef (and, with DDP, the all-reduced FeCL sums)
+        with fctx:
+            g_emb = ops.fecl_bwd(*fargs, float(gw), fst, self.coef[5:6])
+            g_feat = ops.l2norm_bwd(s_emb, s_nrm, g_emb).reshape(s_feat.shape)
+        self.s_eng.backward(g_logits, g_feat)            # head entries replay on self.feat, joins at the bottleneck gradient
 
         # ---- all-reduce, clip, SGD, EMA (:368-372)
         if world > 1:      # bucketed all-reduces were issued during the backward (see __init__); wait for them here
