@@ -213,7 +213,7 @@ class Engine:
     def _sync_to(self, key, g):
         if self.feat_stream is None:
             return
-        cur = torch.cuda.current_stream()
+        cur = ops.cur_stream()
         src = self.Gs.get(key)
         if src is not None and src != cur:
             cur.wait_stream(src)
@@ -235,7 +235,7 @@ class Engine:
     def _put(self, t, g):
         self.G[id(t)] = g
         if self.feat_stream is not None:
-            self.Gs[id(t)] = torch.cuda.current_stream()
+            self.Gs[id(t)] = ops.cur_stream()
 
     def _give(self, t, g):
         cur = self._peek(t)
@@ -293,7 +293,7 @@ class Engine:
                     # CUs the latency-bound dgrad / norm-backward kernels leave idle.  backward() joins the streams at the end.
                     ev = torch.cuda.Event()
                     ev.record()
-                    with torch.cuda.stream(self.wgrad_stream):
+                    with ops.on_stream(self.wgrad_stream):
                         self.wgrad_stream.wait_event(ev)
                         wgrad(gy)
                     gy.record_stream(self.wgrad_stream)
@@ -428,7 +428,7 @@ class Engine:
         if self.feat_stream is None:
             feats = self._head(center, training)
         else:
-            with torch.cuda.stream(self.feat_stream):
+            with ops.on_stream(self.feat_stream):
                 self.feat_stream.wait_event(ready)
                 feats = self._head(center, training)
             center.record_stream(self.feat_stream)
@@ -549,19 +549,19 @@ class Engine:
         self.Gs = {}
         self._put(logits, g_logits)
         if self.feat_stream is not None:
-            with torch.cuda.stream(self.feat_stream):
+            with ops.on_stream(self.feat_stream):
                 self._put(feats, g_feats)                    # produced by the caller on the feature stream
         else:
             self._put(feats, g_feats)
         h0, h1 = self._head_range
         for i in range(len(self.tape) - 1, -1, -1):
             if self.feat_stream is not None and h0 <= i < h1:
-                with torch.cuda.stream(self.feat_stream):   # feature branch: concurrent with the decoder's backward
+                with ops.on_stream(self.feat_stream):   # feature branch: concurrent with the decoder's backward
                     self.tape[i]()
             else:
                 self.tape[i]()
         if self.feat_stream is not None:
-            torch.cuda.current_stream().wait_stream(self.feat_stream)
+            ops.cur_stream().wait_stream(self.feat_stream)
         if self.wgrad_stream is not None:
-            torch.cuda.current_stream().wait_stream(self.wgrad_stream)   # all parameter gradients are complete behind this point
+            ops.cur_stream().wait_stream(self.wgrad_stream)   # all parameter gradients are complete behind this point
         self.tape, self.G = [], {}

@@ -23,8 +23,42 @@ def dt(t: torch.Tensor) -> int:
         raise TypeError(f"unsupported dtype {t.dtype}: the HIP path stores fp32 or bf16") from None
 
 
+# torch.cuda.current_stream() costs several microseconds of Python per call (device-index and availability lookups); a step makes
+# ~500 launches.  Inside `on_stream` contexts (the trainer wraps the whole step, the engine its side-stream sections) the current
+# stream is tracked here; outside of them every op still asks torch.
+_STREAMS = []          # stack of torch.cuda.Stream objects
+
+
+def cur_stream():
+    return _STREAMS[-1] if _STREAMS else torch.cuda.current_stream()
+
+
 def _s():
-    return torch.cuda.current_stream().cuda_stream
+    return _STREAMS[-1].cuda_stream if _STREAMS else torch.cuda.current_stream().cuda_stream
+
+
+class on_stream:
+    """`with on_stream(s)`: make s (a torch.cuda.Stream; None = keep torch's current stream) current for torch AND for the
+    launches of this module.  Nestable."""
+
+    def __init__(self, stream=None):
+        self.stream = stream
+        self.ctx = None
+
+    def __enter__(self):
+        if self.stream is None:
+            _STREAMS.append(torch.cuda.current_stream())
+        else:
+            self.ctx = torch.cuda.stream(self.stream)
+            self.ctx.__enter__()
+            _STREAMS.append(self.stream)
+        return _STREAMS[-1]
+
+    def __exit__(self, *exc):
+        _STREAMS.pop()
+        if self.ctx is not None:
+            self.ctx.__exit__(*exc)
+        return False
 
 
 def _p(t: Optional[torch.Tensor]):

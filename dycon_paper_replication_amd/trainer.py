@@ -167,7 +167,7 @@ class DyconTrainer:
     def _on_param_grads(self, name):
         rng = self._bucket_of.get(name)
         if rng is not None:
-            cur = torch.cuda.current_stream()
+            cur = ops.cur_stream()
             if cur != self._main:      # called from the weight-gradient stream: the bucket also holds norm / bias gradients that
                 ev = torch.cuda.Event()    # the main stream wrote -- the collective must wait for both streams
                 ev.record(self._main)
@@ -188,6 +188,12 @@ class DyconTrainer:
     # ------------------------------------------------------------------ the step
     def step(self, volume, label, noise=None, s_drop: Optional[DropoutSpec] = None, t_drop: Optional[DropoutSpec] = None,
              epoch: Optional[int] = None, beta: Optional[float] = None):
+        """One DyCON iteration (see _step); the enclosing on_stream context caches the current-stream handle for all launches."""
+        with ops.on_stream(None):
+            return self._step(volume, label, noise, s_drop, t_drop, epoch, beta)
+
+    def _step(self, volume, label, noise=None, s_drop: Optional[DropoutSpec] = None, t_drop: Optional[DropoutSpec] = None,
+              epoch: Optional[int] = None, beta: Optional[float] = None):
         """volume (B,1,D,H,W) fp32, label (B,D,H,W) int64|uint8, both on the device.  The first
         ``labeled_bs`` samples are the labelled ones (TwoStreamBatchSampler order, dataloaders/brats19.py:309-314).
 
@@ -216,10 +222,10 @@ class DyconTrainer:
         # The teacher forward (:305-306) is independent of the student forward (:304): it runs on a second HIP stream so the
         # small, launch-latency-bound kernels of the deep levels (6^3, 12^3: 50-100 workgroups on 256 CUs) of the two nets overlap.
         t_train = c.teacher_mode == "train"
-        main = self._main = torch.cuda.current_stream()
+        main = self._main = ops.cur_stream()
         if c.overlap_teacher:
             self.side.wait_stream(main)
-            with torch.cuda.stream(self.side):
+            with ops.on_stream(self.side):
                 self.t_eng.repack()  # the teacher's packs belong to its stream (the EMA update that changed them precedes the fork)
                 t_logits, t_feat, _ = self.t_eng.forward(x_t, training=t_train, record=False, dropout=t_drop, update_bn=t_train)
             x_t.record_stream(self.side)
@@ -235,8 +241,8 @@ class DyconTrainer:
         world = self.world
         glob = world > 1 and c.global_batch_losses
         sums = ops.seg_losses_fwd(s_logits, t_logits, label, LB, beta)
-        fctx = torch.cuda.stream(self.feat) if self.feat is not None else contextlib.nullcontext()
-        with fctx:
+        fctx = (lambda: ops.on_stream(self.feat)) if self.feat is not None else contextlib.nullcontext
+        with fctx():
             if self.feat is not None:                     # teacher features (the student's head was enqueued on self.feat)
                 self.feat.wait_stream(self.side if c.overlap_teacher else main)
                 t_feat.record_stream(self.feat)
@@ -275,7 +281,7 @@ class DyconTrainer:
         g_logits = ops.seg_losses_bwd(s_logits, t_logits, label, LB, beta, sums, self.coef, cons_kind)
         if self.feat is not None:
             self.feat.wait_stream(main)                   # coef (and, with DDP, the all-reduced FeCL sums)
-        with fctx:
+        with fctx():
             g_emb = ops.fecl_bwd(*fargs, float(gw), fst, self.coef[5:6])
             g_feat = ops.l2norm_bwd(s_emb, s_nrm, g_emb).reshape(s_feat.shape)
         self.s_eng.backward(g_logits, g_feat)            # head entries replay on self.feat, joins at the bottleneck gradient
