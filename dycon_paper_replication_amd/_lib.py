@@ -108,5 +108,14 @@ def call(name, *args):
         raise DyconLibraryError(f"{name} failed ({rc}): {lib.dycon_last_error().decode()}")
 
 
+_QUERY_CACHE = {}
+
+
 def query(name, *args):
-    return getattr(load(), name)(*args)
+    """Pure host-side size / plan queries: memoised (a step repeats the same ~200 shapes)."""
+    key = (name,) + args
+    try:
+        return _QUERY_CACHE[key]
+    except KeyError:
+        v = _QUERY_CACHE[key] = getattr(load(), name)(*args)
+        return v

@@ -90,22 +90,38 @@ class KernelProfiler:
 PROFILER: Optional[KernelProfiler] = None
 
 
-class _Region:
+class _Timed:
     __slots__ = ("name", "nbytes", "flops", "e0")
 
     def __init__(self, name, nbytes, flops):
         self.name, self.nbytes, self.flops = name, nbytes, flops
 
     def __enter__(self):
-        if PROFILER is not None:
-            self.e0 = torch.cuda.Event(enable_timing=True)
-            self.e0.record()
+        self.e0 = torch.cuda.Event(enable_timing=True)
+        self.e0.record()
 
     def __exit__(self, *a):
-        if PROFILER is not None:
-            e1 = torch.cuda.Event(enable_timing=True)
-            e1.record()
-            PROFILER.add(self.name, self.e0, e1, self.nbytes, self.flops)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e1.record()
+        PROFILER.add(self.name, self.e0, e1, self.nbytes, self.flops)
+
+
+class _Untimed:
+    __slots__ = ()
+
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *a):
+        return False
+
+
+_UNTIMED = _Untimed()
+
+
+def _Region(name, nbytes, flops):
+    """HIP-event bracket around one entry point while bench.py profiles; a shared no-op object otherwise."""
+    return _UNTIMED if PROFILER is None else _Timed(name, nbytes, flops)
 
 
 def _es(t):
