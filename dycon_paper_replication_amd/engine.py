@@ -292,7 +292,7 @@ class Engine:
                     # second HIP stream (behind an event that marks gy ready) so the small-level wgrad / reduce launches fill the
                     # CUs the latency-bound dgrad / norm-backward kernels leave idle.  backward() joins the streams at the end.
                     ev = torch.cuda.Event()
-                    ev.record()
+                    ev.record(ops.cur_stream())
                     with ops.on_stream(self.wgrad_stream):
                         self.wgrad_stream.wait_event(ev)
                         wgrad(gy)
@@ -418,7 +418,7 @@ class Engine:
         if self.feat_stream is None:
             return None
         ev = torch.cuda.Event()
-        ev.record()
+        ev.record(ops.cur_stream())
         return ev
 
     def _head_branch(self, center, ready, training):

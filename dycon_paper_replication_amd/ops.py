@@ -64,7 +64,8 @@ class on_stream:
 def _p(t: Optional[torch.Tensor]):
     if t is None:
         return None
-    assert t.is_cuda and t.is_contiguous(), "HIP ops need contiguous CUDA tensors"
+    if not (t.is_cuda and t.is_contiguous()):
+        raise ValueError("HIP ops need contiguous CUDA tensors")
     return t.data_ptr()
 
 
@@ -191,10 +192,14 @@ def conv_gemm(x, wfrag, bias, mode, N, Cout, scatter=False, out=None, accumulate
         else:
             shape = (B, D, H, W, N)
         out = torch.empty(shape, dtype=x.dtype, device=x.device)
-    taps = {CONV_K3: 27, CONV_K2S2: 8, CONV_1X1: 1}[mode]
-    rows = out.numel() // Cout if not scatter else x.numel() // Cin
     nws = query("dycon_conv_gemm_workspace", dt(x), mode, int(scatter), B, D, H, W, Cin, N)
     ws = _ws(nws, x) if nws else None
+    if PROFILER is None:      # hot path: no region bookkeeping (a step makes ~90 of these calls)
+        call("dycon_conv_gemm", _p(x), _p(wfrag), _p(bias), _p(out), dt(x), mode, int(scatter), int(accumulate),
+             B, D, H, W, Cin, N, Cout, _p(ws), nws, _s())
+        return out
+    taps = {CONV_K3: 27, CONV_K2S2: 8, CONV_1X1: 1}[mode]
+    rows = out.numel() // Cout if not scatter else x.numel() // Cin
     lds_path = mode == CONV_K3 and not scatter and conv_uses_lds(x, Cin, Cout)
     if lds_path:      # the persistent kernels of the 16-channel level, or the generic LDS-halo kernel
         rname = "conv_k3_p16" if (Cin, Cout) == (16, 16) else ("conv_k3_c1" if Cin == 1 else "conv_k3_lds")
