@@ -72,6 +72,7 @@ def main():
     ap.add_argument("--batch", type=int, default=4)
     ap.add_argument("--labeled", type=int, default=2)
     ap.add_argument("--patch", type=int, nargs=3, default=[96, 96, 96])
+    ap.add_argument("--feature-scaler", type=int, default=2, help="2: BraTS / Pancreas (N = 1728 at 96^3); 4: ISLES (N = 15680 at 112x112x80)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     args = ap.parse_args()
@@ -102,7 +103,8 @@ def main():
     from dycon_paper_replication_amd.trainer import DyconTrainer, TrainConfig
 
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
-    cfg = TrainConfig(model=args.model, batch_size=args.batch, labeled_bs=args.labeled, dtype=dtype, seed=1337)
+    cfg = TrainConfig(model=args.model, batch_size=args.batch, labeled_bs=args.labeled, dtype=dtype, seed=1337,
+                      feature_scaler=args.feature_scaler)
     tr = DyconTrainer(cfg, dev, process_group=pg)
     patch = tuple(args.patch)
     vol, lab, _ = make_batch(1337 + rank, args.batch, patch)
@@ -137,12 +139,15 @@ def main():
 
     # ---- per-kernel roofline (HIP events on the launch stream, a few extra un-timed steps)
     roofline = None
-    if not args.no_kernel_timing and rank == 0:
-        ops.PROFILER = ops.KernelProfiler()
-        nprof = 3
+    nprof = 3
+    if not args.no_kernel_timing:
+        # EVERY rank runs these extra steps (a step contains collectives when world > 1); only rank 0 brackets its launches
+        if rank == 0:
+            ops.PROFILER = ops.KernelProfiler()
         for _ in range(nprof):
             tr.step(vol, lab)
-        torch.cuda.synchronize()
+        barrier()
+    if not args.no_kernel_timing and rank == 0:
         summ = ops.PROFILER.summary()
         ops.PROFILER = None
         # The roofline object describes ONE kernel: pick the dominant region among the entry points that are a single launch
