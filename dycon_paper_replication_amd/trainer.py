@@ -167,11 +167,15 @@ class DyconTrainer:
     def _on_param_grads(self, name):
         rng = self._bucket_of.get(name)
         if rng is not None:
+            # The bucket holds gradients written on up to three streams: conv weights / biases (weight-gradient stream), norm affine
+            # parameters (main) and the projection head's parameters (feature stream, whose backward was enqueued first).  The
+            # collective is ordered after the stream it is issued from: make that stream wait for the other two.
             cur = ops.cur_stream()
-            if cur != self._main:      # called from the weight-gradient stream: the bucket also holds norm / bias gradients that
-                ev = torch.cuda.Event()    # the main stream wrote -- the collective must wait for both streams
-                ev.record(self._main)
-                cur.wait_event(ev)
+            for other in (self._main, self.feat, self.s_eng.wgrad_stream):
+                if other is not None and other != cur:
+                    ev = torch.cuda.Event()
+                    ev.record(other)
+                    cur.wait_event(ev)
             self._pending.append(torch.distributed.all_reduce(self.flat_g[rng[0]:rng[1]], group=self.pg, async_op=True))
 
     # ------------------------------------------------------------------ schedules (host scalars)
