@@ -395,6 +395,10 @@ __global__ __launch_bounds__(256) void fecl_kernel(const T* __restrict__ F, cons
     E* Fj = lds + FT * stride;
     E* Tt = Fj + FT * stride;                          // PASS 4 only: 64 x 64 pair-weight tile
     constexpr int tstride = FT + FeclTile<T>::TPAD;
+    // per-column statistics of the current column tile {max, negative sum, kappa, H, mask}[64]: loaded (and the column-split
+    // slabs combined) ONCE per tile by 64 threads instead of by every lane for each of its four columns (at N = 15680 the
+    // per-lane global loads were what the pair epilogue waited on)
+    float* cst = reinterpret_cast<float*>(lds_raw + (((size_t)2 * FT * stride + (PASS == 4 ? FT * tstride : 0)) * sizeof(E) + 15) / 16 * 16);
     const int b = blockIdx.y, i0 = blockIdx.x * FT;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 15, kg = lane >> 4;
@@ -449,6 +453,17 @@ __global__ __launch_bounds__(256) void fecl_kernel(const T* __restrict__ F, cons
     for (int j0 = j_beg; j0 < j_end; j0 += FT) {
         __syncthreads();
         stage_rows(Fj, stride, Dp, Fb, j0, N, Dm);
+        if (PASS >= 2 && threadIdx.x < FT) {
+            const int gc = j0 + threadIdx.x;
+            const bool vc = gc < N;
+            cst[threadIdx.x] = vc ? ld_max(wm, rb + gc) : 0.f;
+            cst[4 * FT + threadIdx.x] = vc ? mb[gc] : -2.f;
+            if (PASS == 4) {
+                cst[FT + threadIdx.x] = vc ? ld_sum(wn, rb + gc) : 0.f;
+                cst[2 * FT + threadIdx.x] = vc ? wk[rb + gc] : 0.f;
+                cst[3 * FT + threadIdx.x] = vc ? ld_sum(wh, rb + gc) : 0.f;
+            }
+        }
         __syncthreads();
         f32x4 acc[4];
         gram_tile(Fi, Fj, stride, nq, wave, lane, acc);
@@ -466,7 +481,7 @@ __global__ __launch_bounds__(256) void fecl_kernel(const T* __restrict__ F, cons
             for (int j = 0; j < 4; ++j) {
                 const int gj = j0 + 16 * j + r;
                 if (gj >= N) continue;
-                const float mj = ld_max(wm, rb + gj), mk = mb[gj];
+                const float mj = cst[16 * j + r], mk = cst[4 * FT + 16 * j + r];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     if (mk == mrow[i]) a1[i] += 1.f;
@@ -478,7 +493,7 @@ __global__ __launch_bounds__(256) void fecl_kernel(const T* __restrict__ F, cons
             for (int j = 0; j < 4; ++j) {
                 const int gj = j0 + 16 * j + r;
                 if (gj >= N) continue;
-                const float mj = ld_max(wm, rb + gj), mk = mb[gj];
+                const float mj = cst[16 * j + r], mk = cst[4 * FT + 16 * j + r];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     if (mk == mrow[i]) {
@@ -500,8 +515,8 @@ __global__ __launch_bounds__(256) void fecl_kernel(const T* __restrict__ F, cons
             for (int j = 0; j < 4; ++j) {
                 const int gj = j0 + 16 * j + r;
                 const bool vj = gj < N;
-                const float mj = vj ? ld_max(wm, rb + gj) : 0.f, mk = vj ? mb[gj] : -2.f;
-                const float nj = vj ? ld_sum(wn, rb + gj) : 0.f, kj = vj ? wk[rb + gj] : 0.f, hj = vj ? ld_sum(wh, rb + gj) : 0.f;
+                const int cc = 16 * j + r;
+                const float mj = cst[cc], mk = cst[4 * FT + cc], nj = cst[FT + cc], kj = cst[2 * FT + cc], hj = cst[3 * FT + cc];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     float tv = 0.f;
@@ -537,7 +552,7 @@ __global__ __launch_bounds__(256) void fecl_kernel(const T* __restrict__ F, cons
             for (int j = 0; j < 4; ++j) {
                 const int gj = j0 + 16 * j + r;
                 const bool vj = gj < N;
-                const float mk = vj ? mb[gj] : -2.f;
+                const float mk = cst[4 * FT + 16 * j + r];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const float sx = acc[j][i];
@@ -717,6 +732,7 @@ template <typename T> static size_t fecl_lds_bytes(int Dm, bool grad) {
     typedef FeclTile<T> G;
     const int Dp = (Dm + G::KS - 1) / G::KS * G::KS, stride = Dp + G::PAD;
     size_t n = ((size_t)2 * FT * stride + (grad ? FT * (FT + G::TPAD) : 0)) * sizeof(typename G::E);
+    n = (n + 15) / 16 * 16 + 5 * FT * sizeof(float);   // + per-column statistics of the current tile
     return n < 256 ? 256 : n;   // the pass-3 block reduction borrows the first floats
 }
 
