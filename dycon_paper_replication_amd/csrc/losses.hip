@@ -376,6 +376,20 @@ __device__ __forceinline__ void focal_terms(float P, float gamma, int focal, flo
     dphi = -fdiv<FAST>(w, P + eps) + dw * lg;
 }
 
+// bf16 storage, focal gamma = 2 (the configuration every script runs): the same-class pair terms with the divisions folded away.
+// With a = exp(L - m), d = a + n, r = 1/d:  P = a r, 1 - P = n r, log P = (L - m) - log d, and
+//   phi(P)            = -log P (1 - P)^2
+//   a * dphi/dP       = -(1-P)^2 d + 2 (1-P) a log P = n r (2 a log P - n)
+// so one exp, one rcp and one log per direction replace one exp, one log and four divisions (the 1e-18 guards of the reference
+// formula only matter for d < 1e-15, which a + n never is: n counts at least exp(-2/tau) per other-class column).
+__device__ __forceinline__ void fast_pair(float lm /* L - m */, float n, float& a, float& r, float& lgP, float& adphi) {
+    a = __expf(lm);
+    const float d = a + n;
+    r = __frcp_rn(d);
+    lgP = lm - __logf(d);
+    adphi = n * r * (2.f * a * lgP - n);
+}
+
 // PASS: 1 row max | 2 negative sums + class counts | 3 loss + H (+ cross sums) | 4 gradient
 template <typename T, int PASS>
 __global__ __launch_bounds__(256) void fecl_kernel(const T* __restrict__ F, const T* __restrict__ Tch,
@@ -443,6 +457,7 @@ __global__ __launch_bounds__(256) void fecl_kernel(const T* __restrict__ F, cons
 #pragma unroll
         for (int t = 0; t < MAXNT; ++t) gacc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
+    const float inv_tau = 1.f / tau;
     float cross_scale = 0.f, stud_scale = 0.f;
     if (PASS == 4) {
         stud_scale = coef[0] / (float)BN;
@@ -485,7 +500,7 @@ __global__ __launch_bounds__(256) void fecl_kernel(const T* __restrict__ F, cons
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     if (mk == mrow[i]) a1[i] += 1.f;
-                    else a0[i] += fexp<FAST>(fdiv<FAST>(acc[j][i], tau) - mj);
+                    else a0[i] += FAST ? __expf(acc[j][i] * inv_tau - mj) : expf(acc[j][i] / tau - mj);
                 }
             }
         } else if (PASS == 3) {
@@ -498,7 +513,13 @@ __global__ __launch_bounds__(256) void fecl_kernel(const T* __restrict__ F, cons
                 for (int i = 0; i < 4; ++i) {
                     if (mk == mrow[i]) {
                         a1[i] += 1.f;
-                        if (gj != gi[i]) {
+                        if (gj != gi[i] && FAST && focal && gamma == 2.f) {
+                            float a, rr, lgP, adphi;
+                            fast_pair(acc[j][i] * inv_tau - mj, nrow[i], a, rr, lgP, adphi);
+                            const float om = nrow[i] * rr;
+                            a0[i] += -lgP * om * om;                      // phi
+                            hrow[i] -= adphi * rr * rr;                   // dphi * (-a / d^2)
+                        } else if (gj != gi[i]) {
                             const float a = fexp<FAST>(fdiv<FAST>(acc[j][i], tau) - mj);
                             const float den = a + nrow[i] + 1e-18f;
                             const float P = fdiv<FAST>(a, den);
@@ -520,7 +541,19 @@ __global__ __launch_bounds__(256) void fecl_kernel(const T* __restrict__ F, cons
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     float tv = 0.f;
-                    if (vj && vi[i] && gj != gi[i]) {
+                    if (FAST && focal && gamma == 2.f && vj && vi[i] && gj != gi[i]) {
+                        const float l = acc[j][i] * inv_tau;
+                        if (mk == mrow[i]) {     // tv = a kappa dphi n / d^2 for both directions
+                            float a, rr, lgP, adphi;
+                            fast_pair(l - mj, nrow[i], a, rr, lgP, adphi);
+                            tv = krow[i] * nrow[i] * rr * rr * adphi;
+                            fast_pair(l - mi[i], nj, a, rr, lgP, adphi);
+                            tv += kj * nj * rr * rr * adphi;
+                        } else {
+                            tv = __expf(l - mj) * hrow[i] + __expf(l - mi[i]) * hj;
+                        }
+                        tv *= stud_scale * inv_tau;
+                    } else if (vj && vi[i] && gj != gi[i]) {
                         const float l = fdiv<FAST>(acc[j][i], tau);
                         const float aij = fexp<FAST>(l - mj), aji = fexp<FAST>(l - mi[i]);
                         if (mk == mrow[i]) {
