@@ -465,9 +465,38 @@ __global__ __launch_bounds__(256) void fecl_kernel(const T* __restrict__ F, cons
     }
 
     const int j_beg = cs * tiles_per_split * FT, j_end = min(N, (cs + 1) * tiles_per_split * FT);
+    // bf16 rows in 16-byte pieces: the NEXT tile to be staged (the teacher rows of this column tile, or the student rows of the
+    // next one) is requested into registers before the current tile's MFMAs / pair epilogue and written to LDS behind the barrier
+    // that retires it -- the global round trip no longer sits between two barriers with nothing else to do.
+    constexpr int NPF = 8;                                // 64 rows x 256 bf16 = 2048 pieces / 256 threads
+    // (not in the gradient pass: its 64 accumulator registers plus a staged tile leave room for one wave per SIMD only -- measured slower)
+    const bool pref = PASS != 4 && sizeof(T) == 2 && (Dm & 7) == 0 && Dp <= 256;
+    uint4 pfr[NPF];
+    auto prefetch = [&](const T* src, int row0) {
+        const unsigned short* s16 = reinterpret_cast<const unsigned short*>(src);
+        const int ppr = Dp >> 3;
+#pragma unroll
+        for (int it = 0; it < NPF; ++it) {
+            const int e = threadIdx.x + 256 * it;
+            const int rr = e / ppr, k = (e - rr * ppr) << 3;
+            pfr[it] = make_uint4(0, 0, 0, 0);
+            if (e < FT * ppr && row0 + rr < N && k < Dm) pfr[it] = *reinterpret_cast<const uint4*>(s16 + (long long)(row0 + rr) * Dm + k);
+        }
+    };
+    auto commit = [&]() {
+        const int ppr = Dp >> 3;
+#pragma unroll
+        for (int it = 0; it < NPF; ++it) {
+            const int e = threadIdx.x + 256 * it;
+            const int rr = e / ppr, k = (e - rr * ppr) << 3;
+            if (e < FT * ppr) *reinterpret_cast<uint4*>(reinterpret_cast<unsigned short*>(Fj) + rr * stride + k) = pfr[it];
+        }
+    };
+    const bool has_cross = (PASS == 3 || PASS == 4) && Tb;
+    if (pref && j_beg < j_end) prefetch(Fb, j_beg);
     for (int j0 = j_beg; j0 < j_end; j0 += FT) {
         __syncthreads();
-        stage_rows(Fj, stride, Dp, Fb, j0, N, Dm);
+        if (pref) commit(); else stage_rows(Fj, stride, Dp, Fb, j0, N, Dm);
         if (PASS >= 2 && threadIdx.x < FT) {
             const int gc = j0 + threadIdx.x;
             const bool vc = gc < N;
@@ -480,6 +509,10 @@ __global__ __launch_bounds__(256) void fecl_kernel(const T* __restrict__ F, cons
             }
         }
         __syncthreads();
+        if (pref) {
+            if (has_cross) prefetch(Tb, j0);
+            else if (j0 + FT < j_end) prefetch(Fb, j0 + FT);
+        }
         f32x4 acc[4];
         gram_tile(Fi, Fj, stride, nq, wave, lane, acc);
 
@@ -578,8 +611,9 @@ __global__ __launch_bounds__(256) void fecl_kernel(const T* __restrict__ F, cons
 
         if ((PASS == 3 || PASS == 4) && Tb) {   // cross branch against the teacher rows of this column tile
             __syncthreads();
-            stage_rows(Fj, stride, Dp, Tb, j0, N, Dm);
+            if (pref) commit(); else stage_rows(Fj, stride, Dp, Tb, j0, N, Dm);
             __syncthreads();
+            if (pref && j0 + FT < j_end) prefetch(Fb, j0 + FT);
             gram_tile(Fi, Fj, stride, nq, wave, lane, acc);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
