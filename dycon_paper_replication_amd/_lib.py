@@ -68,6 +68,7 @@ SIGNATURES = {
     "dycon_sw_accumulate": (I, [P, I, I, I, I, P, P, P, I, I, I, P]),
     "dycon_sw_finalize": (I, [P, P, L, F, P, P, P]),
     "dycon_binary_overlap": (I, [P, P, I, L, P, P]),
+    "dycon_batch_overlap": (I, [P, P, I, I, L, P, P]),
 }
 
 

@@ -58,6 +58,42 @@ __global__ __launch_bounds__(256) void binary_overlap_kernel(const unsigned char
     if (threadIdx.x < 3) atomicAdd(out + threadIdx.x, sm[threadIdx.x][0] + sm[threadIdx.x][1] + sm[threadIdx.x][2] + sm[threadIdx.x][3]);
 }
 
+// Train-time batch metrics (code/train_DyCON_BraTS19.py:385-392): per sample {|pred|, |gt|, |pred & gt|} with pred = softmax(logits)[1] > 0.5
+// (<=> logit 1 > logit 0), straight from the student logits -- the reference materialises the probability and binary volumes first.
+template <typename TG>
+__global__ __launch_bounds__(256) void batch_overlap_kernel(const float2* __restrict__ logits, const TG* __restrict__ gt, long long V,
+                                                            unsigned long long* __restrict__ out) {
+    __shared__ unsigned long long sm[3][4];
+    const int b = blockIdx.y;
+    unsigned long long a = 0, g_ = 0, c = 0;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < V; i += (long long)gridDim.x * 256) {
+        const float2 l = logits[(long long)b * V + i];
+        const bool p = l.y > l.x, g = gt[(long long)b * V + i] != 0;
+        a += p;
+        g_ += g;
+        c += p && g;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); g_ += __shfl_xor(g_, o, 64); c += __shfl_xor(c, o, 64); }
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) { sm[0][w] = a; sm[1][w] = g_; sm[2][w] = c; }
+    __syncthreads();
+    if (threadIdx.x < 3) atomicAdd(out + 3 * b + threadIdx.x, sm[threadIdx.x][0] + sm[threadIdx.x][1] + sm[threadIdx.x][2] + sm[threadIdx.x][3]);
+}
+
+extern "C" int dycon_batch_overlap(const float* logits, const void* gt, int gt_bytes, int B, long long V, unsigned long long* out3b,
+                                   dycon_stream_t stream) {
+    DYCON_REQUIRE(logits && gt && out3b && B > 0 && B <= 65535 && V > 0, "batch_overlap: bad arguments");
+    DYCON_REQUIRE(gt_bytes == 1 || gt_bytes == 8, "batch_overlap: ground truth must be uint8 or int64");
+    long long blocks = (V + 255) / 256;
+    if (blocks > 512) blocks = 512;
+    dim3 grid((int)blocks, B);
+    if (gt_bytes == 1) batch_overlap_kernel<unsigned char><<<grid, 256, 0, stream>>>((const float2*)logits, (const unsigned char*)gt, V, out3b);
+    else batch_overlap_kernel<long long><<<grid, 256, 0, stream>>>((const float2*)logits, (const long long*)gt, V, out3b);
+    DYCON_LAUNCH_CHECK();
+    return DYCON_OK;
+}
+
 extern "C" int dycon_sw_accumulate(const float* logits, int n_patches, int p0, int p1, int p2, const int* origins_dev, float* score,
                                    float* cnt, int D0, int D1, int D2, dycon_stream_t stream) {
     DYCON_REQUIRE(logits && origins_dev && score && cnt, "sw_accumulate: null pointer");

@@ -259,6 +259,12 @@ int dycon_sw_finalize(const float* score, const float* cnt, long long n, float t
 int dycon_binary_overlap(const uint8_t* pred, const void* gt, int gt_bytes, long long n,
                          unsigned long long* out3, dycon_stream_t stream);
 
+/* Train-time batch metrics (train_DyCON_BraTS19.py:385-392; utils/metrics.py compute_dice / compute_jaccard): for each sample b
+ * out3b[3b..3b+2] (device, caller zeroes) += { |pred|, |gt|, |pred & gt| } with pred = softmax(logits)[1] > 0.5, read straight from
+ * the (B, V, 2) fp32 logits. */
+int dycon_batch_overlap(const float* logits, const void* gt, int gt_bytes, int B, long long V,
+                        unsigned long long* out3b, dycon_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

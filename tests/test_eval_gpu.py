@@ -73,3 +73,35 @@ def test_all_case_bf16_close_to_fp32():
     assert np.abs(s32 - s16).max() < 5e-2
     both = l32.sum() + l16.sum()
     assert both == 0 or 2.0 * (l32 & l16).sum() / both > 0.97
+
+
+def test_train_time_metrics():
+    """batch Dice / Jaccard counted on the device from the logits (no materialised probability volume), HD95 off the
+    critical path; against the reference's formulas in numpy."""
+    import time
+    from dycon_paper_replication_amd.utils import metrics as M
+    rng = np.random.default_rng(3)
+    B, shape = 3, (24, 20, 16)
+    logits = torch.from_numpy(rng.standard_normal((B,) + shape + (2,)).astype(np.float32)).cuda()
+    label = torch.from_numpy((rng.random((B,) + shape) > 0.6).astype(np.int64)).cuda()
+    pred = (torch.softmax(logits, -1)[..., 1] > 0.5).float()
+    inter = (pred * label).sum((1, 2, 3))
+    ref_dice = (2 * inter / (pred.sum((1, 2, 3)) + label.sum((1, 2, 3)) + 1e-8)).cpu().numpy()
+    ref_jac = (inter / (pred.sum((1, 2, 3)) + label.sum((1, 2, 3)) - inter + 1e-8)).cpu().numpy()
+    np.testing.assert_allclose(M.batch_dice_from_logits(logits, label).cpu().numpy(), ref_dice, rtol=1e-6)
+    np.testing.assert_allclose(M.batch_dice_from_logits(logits.permute(0, 4, 1, 2, 3), label).cpu().numpy(), ref_dice, rtol=1e-6)
+    np.testing.assert_allclose(M.compute_dice(pred, label).cpu().numpy(), ref_dice, rtol=1e-6)
+    np.testing.assert_allclose(M.compute_jaccard(pred, label.to(torch.uint8)).cpu().numpy(), ref_jac, rtol=1e-6)
+    hd = M.compute_hd95(pred, label, 99.0)
+    assert len(hd) == B and all(0 <= h < 99.0 for h in hd)
+    assert M.compute_hd95(torch.zeros_like(pred), label, 99.0) == [99.0] * B          # empty prediction -> max_dist
+    m = M.AsyncTrainMetrics(every=1)
+    m.update(0, logits, label)
+    for _ in range(200):
+        if m.latest()["hd95"] is not None:
+            break
+        time.sleep(0.01)
+    got = m.latest()
+    m.close()
+    assert got["hd95"] is not None and got["hd95"][1] == pytest.approx(float(np.mean(hd)))
+    np.testing.assert_allclose(got["dice"].cpu().numpy(), ref_dice, rtol=1e-6)
