@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """DyCON training-step benchmark on MI355X (contract: see the task description / DESIGN.md section 4).
 
-    python bench.py --gpus 1 --steps 20 --warmup 5
+    python bench.py --gpus 1 --steps 50 --warmup 10
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
            bench.py --gpus N --steps K --warmup W
 
@@ -65,8 +65,8 @@ def cpu_baseline(model, patch, seed):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=50)      # warm-up 10, time >= 50 steps (60 steps = 0.4 s on the GPU)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--model", default="vnet", choices=["vnet", "unet_3D"])
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--batch", type=int, default=4)

@@ -147,6 +147,7 @@ class Engine:
         self.feat_stream = None      # optional stream for the feature branch (projection head forward + backward), see forward()
         self.Gs = {}
         self._head_range = (0, 0)
+        self._wws = {}               # per-layer workspaces of the weight-gradient launches
         self.tape = []
         self.G = {}
 
@@ -277,11 +278,19 @@ class Engine:
         if self.recording:
             def wgrad(gy):
                 gw, gb = self.g[name + ".weight"], self.g[name + ".bias"]
+                # workspaces of the weight-gradient launches are kept per layer: on the side stream nothing may be allocated
+                # (the section only redirects this module's launches, torch's current stream -- and allocator pool -- stays put)
+                ws = self._wws.get(name)
                 if kind == "deconv":   # dW[ci][co][t] = sum_m x[m,ci] * gy[2m+t,co]   (roles of x and gy swapped)
-                    ops.colsum(gy, gb)
-                    ops.conv_wgrad(gy, x, gw, CONV_K2S2, 1, 8, Cout * 8)
+                    if ws is None:
+                        ws = self._wws[name] = (ops._ws(ops.query("dycon_colsum_workspace", gy.numel() // gy.shape[-1], gy.shape[-1]), gy),
+                                                ops.conv_wgrad_workspace(gy, x, CONV_K2S2))
+                    ops.colsum(gy, gb, ws=ws[0])
+                    ops.conv_wgrad(gy, x, gw, CONV_K2S2, 1, 8, Cout * 8, ws=ws[1])
                 else:                  # bias gradient = column sums of gy, fused into the wgrad pass
-                    ops.conv_wgrad(x, gy, gw, mode, 1 if T > 1 else 0, T, Cin * T, dbias=gb)
+                    if ws is None:
+                        ws = self._wws[name] = ops.conv_wgrad_workspace(x, gy, mode)
+                    ops.conv_wgrad(x, gy, gw, mode, 1 if T > 1 else 0, T, Cin * T, dbias=gb, ws=ws)
                 if self.on_param_grads is not None:
                     self.on_param_grads(name + ".weight")      # this layer's gradients are enqueued (DDP bucket trigger)
 
@@ -293,8 +302,8 @@ class Engine:
                     # CUs the latency-bound dgrad / norm-backward kernels leave idle.  backward() joins the streams at the end.
                     ev = torch.cuda.Event()
                     ev.record(ops.cur_stream())
-                    with ops.on_stream(self.wgrad_stream):
-                        self.wgrad_stream.wait_event(ev)
+                    self.wgrad_stream.wait_event(ev)
+                    with ops.on_stream(self.wgrad_stream, light=True):
                         wgrad(gy)
                     gy.record_stream(self.wgrad_stream)
                 else:

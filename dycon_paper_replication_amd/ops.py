@@ -39,15 +39,19 @@ def _s():
 
 class on_stream:
     """`with on_stream(s)`: make s (a torch.cuda.Stream; None = keep torch's current stream) current for torch AND for the
-    launches of this module.  Nestable."""
+    launches of this module.  Nestable.  light=True redirects only this module's launches (no torch stream switch, which costs
+    ~10 us of host time per enter/exit): for sections that allocate nothing and call no torch op."""
 
-    def __init__(self, stream=None):
+    def __init__(self, stream=None, light=False):
         self.stream = stream
+        self.light = light
         self.ctx = None
 
     def __enter__(self):
         if self.stream is None:
             _STREAMS.append(torch.cuda.current_stream())
+        elif self.light:
+            _STREAMS.append(self.stream)
         else:
             self.ctx = torch.cuda.stream(self.stream)
             self.ctx.__enter__()
@@ -228,13 +232,19 @@ def conv_direct(x, w_tcn, bias, mode, N, out_dtype, out=None, accumulate=False):
     return out
 
 
-def conv_wgrad(x, gy, dw, mode, s_t, s_c, s_n, dbias=None):
+def conv_wgrad_workspace(x, gy, mode):
+    """A workspace tensor for conv_wgrad of these shapes (callers that run on a side stream keep one per layer)."""
+    B, D, H, W, Cin = x.shape
+    return _ws(query("dycon_conv_wgrad_workspace", mode, B, D, H, W, Cin, gy.shape[-1]), x)
+
+
+def conv_wgrad(x, gy, dw, mode, s_t, s_c, s_n, dbias=None, ws=None):
     """dw[t*s_t + c*s_c + n*s_n] = sum_rows x[src(row,t), c] * gy[row, n]; dw is an fp32 tensor (any shape).
     dbias (optional, fp32 (Cout,)): column sums of gy, fused into the same pass where the kernel allows."""
     B, D, H, W, Cin = x.shape
     Cout = gy.shape[-1]
-    nbytes = query("dycon_conv_wgrad_workspace", mode, B, D, H, W, Cin, Cout)
-    ws = _ws(nbytes, x)
+    if ws is None:
+        ws = _ws(query("dycon_conv_wgrad_workspace", mode, B, D, H, W, Cin, Cout), x)
     taps = {CONV_K3: 27, CONV_K2S2: 8, CONV_1X1: 1}[mode]
     k3bf = (x.dtype == torch.bfloat16 and gy.dtype == torch.bfloat16 and mode == CONV_K3 and (Cin % 16 == 0 or Cin == 1)
             and (Cout in (16, 32) or Cout % 64 == 0))
@@ -245,11 +255,12 @@ def conv_wgrad(x, gy, dw, mode, s_t, s_c, s_n, dbias=None):
     return dw
 
 
-def colsum(x2d_like, out):
+def colsum(x2d_like, out, ws=None):
     """out[c] = sum over all leading dims of x[..., c]."""
     C = x2d_like.shape[-1]
     rows = x2d_like.numel() // C
-    ws = _ws(query("dycon_colsum_workspace", rows, C), x2d_like)
+    if ws is None:
+        ws = _ws(query("dycon_colsum_workspace", rows, C), x2d_like)
     with _Region("colsum", x2d_like.numel() * _es(x2d_like), x2d_like.numel()):
         call("dycon_colsum", _p(x2d_like), dt(x2d_like), _p(out), rows, C, _p(ws), ws.numel() * 4, _s())
     return out

@@ -170,8 +170,8 @@ class DyconTrainer:
             # The bucket holds gradients written on up to three streams: conv weights / biases (weight-gradient stream), norm affine
             # parameters (main) and the projection head's parameters (feature stream, whose backward was enqueued first).  The
             # collective is ordered after the stream it is issued from: make that stream wait for the other two.
-            cur = ops.cur_stream()
-            for other in (self._main, self.feat, self.s_eng.wgrad_stream):
+            cur = torch.cuda.current_stream()     # the stream torch.distributed orders the collective after (the weight-gradient
+            for other in (self._main, self.feat, self.s_eng.wgrad_stream):   # section redirects only this package's launches)
                 if other is not None and other != cur:
                     ev = torch.cuda.Event()
                     ev.record(other)
