@@ -429,7 +429,13 @@ __global__ __launch_bounds__(256) void conv_k3_lds_kernel(const bf16* __restrict
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 15, kg = lane >> 4;
     const int wm = wave / WN, wn = wave % WN;
+    // Workgroups are dealt to the 8 XCDs round-robin: give every XCD one contiguous range of tiles, so that the halo overlap
+    // between neighbouring tiles is served by that XCD's L2 instead of being fetched into two of them
     int tile = blockIdx.x;
+    {
+        const int nT = gridDim.x, per = nT >> 3;
+        if (per > 0 && tile < per * 8) tile = (tile & 7) * per + (tile >> 3);
+    }
     const int tx = tile % tilesX; tile /= tilesX;
     const int ty = tile % tilesY; tile /= tilesY;
     const int tz = tile % tilesZ;
