@@ -1166,12 +1166,16 @@ __global__ __launch_bounds__(256, 2) void wgrad_k3_bf16_kernel(const bf16* __res
         }
     };
 
-    if ((int)blockIdx.y < nTiles) load_tile(blockIdx.y);
-    for (int tile = blockIdx.y; tile < nTiles; tile += gridDim.y) {
+    // every split walks ONE contiguous range of tiles (not a stride of gridDim.y): consecutive tiles share halo planes, which the
+    // workgroup then finds in its XCD's L2
+    const int t_per = (nTiles + (int)gridDim.y - 1) / (int)gridDim.y;
+    const int t_beg = blockIdx.y * t_per, t_end = min(nTiles, t_beg + t_per);
+    if (t_beg < t_end) load_tile(t_beg);
+    for (int tile = t_beg; tile < t_end; ++tile) {
         __syncthreads();   // previous tile fully consumed
         store_tile();
         __syncthreads();
-        if (tile + (int)gridDim.y < nTiles) load_tile(tile + gridDim.y);
+        if (tile + 1 < t_end) load_tile(tile + 1);
         // ---- 4 k-steps of 32 voxels: lane group kg owns x-row (z, y) = ((4s+kg)>>2, (4s+kg)&3), voxels x = 0..7
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
@@ -1258,7 +1262,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_k2s2_bf16_kernel(const bf16* __r
     for (int j = 0; j < NT; ++j) bsum[j] = 0.f;
     const bool do_bias = bias_part != nullptr && ci0 == 0 && wave == 0;
 
-    for (int tile = blockIdx.y; tile < nTiles; tile += gridDim.y) {
+    const int t_per = (nTiles + (int)gridDim.y - 1) / (int)gridDim.y;      // one contiguous tile range per split (L2 locality)
+    const int t_beg = blockIdx.y * t_per, t_end = min(nTiles, t_beg + t_per);
+    for (int tile = t_beg; tile < t_end; ++tile) {
         int rr = tile;
         const int tx = rr % tilesX; rr /= tilesX;
         const int ty = rr % tilesY; rr /= tilesY;
