@@ -101,12 +101,37 @@ def load():
     return lib
 
 
+class Recorder:
+    """Software command buffer of one training step (trainer.DyconTrainer, `replay`): every C-ABI call is logged as
+    [function, argument list, name] and every torch-level stream / event / tensor operation as a thunk, in issue order; tensors whose
+    addresses were passed are kept alive, so the same list can be re-issued step after step with only the schedule scalars patched.
+    (hipGraph replay of the same step costs more host time than this list: DESIGN.md section 9.)"""
+
+    def __init__(self):
+        self.entries, self.keep = [], []
+
+    def replay(self):
+        for e in self.entries:
+            if type(e) is list:
+                rc = e[0](*e[1])
+                if rc:
+                    raise DyconLibraryError(f"{e[2]} failed ({rc}) in replay: {load().dycon_last_error().decode()}")
+            else:
+                e()
+
+
+RECORDER = None
+
+
 def call(name, *args):
     """Invoke an int-returning entry point; raise with dycon_last_error() on failure."""
     lib = load()
-    rc = getattr(lib, name)(*args)
+    fn = getattr(lib, name)
+    rc = fn(*args)
     if rc != 0:
         raise DyconLibraryError(f"{name} failed ({rc}): {lib.dycon_last_error().decode()}")
+    if RECORDER is not None:
+        RECORDER.entries.append([fn, list(args), name])
 
 
 _QUERY_CACHE = {}

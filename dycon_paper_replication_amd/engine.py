@@ -217,7 +217,7 @@ class Engine:
         cur = ops.cur_stream()
         src = self.Gs.get(key)
         if src is not None and src != cur:
-            cur.wait_stream(src)
+            ops.rec(lambda: cur.wait_stream(src))
             g.record_stream(cur)
 
     def _take(self, t):
@@ -300,9 +300,8 @@ class Engine:
                     # The weight gradient only feeds the optimiser; the data gradient is the critical chain.  Enqueue the former on a
                     # second HIP stream (behind an event that marks gy ready) so the small-level wgrad / reduce launches fill the
                     # CUs the latency-bound dgrad / norm-backward kernels leave idle.  backward() joins the streams at the end.
-                    ev = torch.cuda.Event()
-                    ev.record(ops.cur_stream())
-                    self.wgrad_stream.wait_event(ev)
+                    ev, cs, ws_ = torch.cuda.Event(), ops.cur_stream(), self.wgrad_stream
+                    ops.rec(lambda: (ev.record(cs), ws_.wait_event(ev)))
                     with ops.on_stream(self.wgrad_stream, light=True):
                         wgrad(gy)
                     gy.record_stream(self.wgrad_stream)
@@ -361,7 +360,8 @@ class Engine:
             y, stats = ops.norm_fwd(z, Nb, V, C, G, gamma, beta, relu, skip, chan_scale, 1e-5, rm if upd else None,
                                     rv if upd else None, 0.1)
             if upd and prefix + ".num_batches_tracked" in self.buf:
-                self.buf[prefix + ".num_batches_tracked"] += 1
+                nbt = self.buf[prefix + ".num_batches_tracked"]
+                ops.rec(lambda: nbt.add_(1))
         if self.recording:
             def bwd():
                 gy = self._take(y)
@@ -426,8 +426,8 @@ class Engine:
     def _mark_ready(self):
         if self.feat_stream is None:
             return None
-        ev = torch.cuda.Event()
-        ev.record(ops.cur_stream())
+        ev, cs = torch.cuda.Event(), ops.cur_stream()
+        ops.rec(lambda: ev.record(cs))
         return ev
 
     def _head_branch(self, center, ready, training):
@@ -438,7 +438,8 @@ class Engine:
             feats = self._head(center, training)
         else:
             with ops.on_stream(self.feat_stream):
-                self.feat_stream.wait_event(ready)
+                fs = self.feat_stream
+                ops.rec(lambda: fs.wait_event(ready))
                 feats = self._head(center, training)
             center.record_stream(self.feat_stream)
         self._head_range = (h0, len(self.tape))
@@ -569,8 +570,11 @@ class Engine:
                     self.tape[i]()
             else:
                 self.tape[i]()
+        cs = ops.cur_stream()
         if self.feat_stream is not None:
-            ops.cur_stream().wait_stream(self.feat_stream)
+            fs = self.feat_stream
+            ops.rec(lambda: cs.wait_stream(fs))
         if self.wgrad_stream is not None:
-            ops.cur_stream().wait_stream(self.wgrad_stream)   # all parameter gradients are complete behind this point
+            ws_ = self.wgrad_stream
+            ops.rec(lambda: cs.wait_stream(ws_))              # all parameter gradients are complete behind this point
         self.tape, self.G = [], {}

@@ -70,7 +70,17 @@ def _p(t: Optional[torch.Tensor]):
         return None
     if not (t.is_cuda and t.is_contiguous()):
         raise ValueError("HIP ops need contiguous CUDA tensors")
+    if _lib.RECORDER is not None:
+        _lib.RECORDER.keep.append(t)        # the recorded call holds the raw address: keep the storage alive
     return t.data_ptr()
+
+
+def rec(thunk):
+    """Run a torch-level operation of the step (stream wait, event record, tensor op) and, while a step is being recorded, log
+    it so that the replay re-issues it at the same position.  The thunk must name its streams explicitly."""
+    thunk()
+    if _lib.RECORDER is not None:
+        _lib.RECORDER.entries.append(thunk)
 
 
 # ------------------------------------------------------------------ optional per-kernel timing (bench.py)

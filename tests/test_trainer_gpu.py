@@ -205,3 +205,24 @@ def test_isles_variants_vs_oracle(net):
             ("conv1.conv1.0.weight", "center.conv1.0.weight", "out_conv2.weight"):
         np.testing.assert_allclose(tr.p[k].cpu().numpy(), st.student[k].numpy(), rtol=2e-4, atol=2e-6, err_msg=k)
         np.testing.assert_allclose(tr.t[k].cpu().numpy(), st.teacher[k].numpy(), rtol=2e-4, atol=2e-6, err_msg="teacher " + k)
+
+
+@pytest.mark.parametrize("net", ["vnet", "unet_3D"])
+def test_replay_equals_eager(net):
+    """cfg.replay: steps 1-2 run eagerly, step 3 is recorded, steps 4+ re-issue the recorded launch list with patched scalars
+    (Philox offsets, schedules) and the batch copied into the recorded input buffers.  Seven steps with changing batches must
+    give the same parameters, teacher and loss sequence as seven eager steps (on-device Philox dropout and noise active)."""
+    from dycon_paper_replication_amd.synthetic import make_batch
+    batches = [make_batch(500 + i, 2, (32, 32, 32)) for i in range(7)]
+    runs = {}
+    for replay in (False, True):
+        tr = DyconTrainer(TrainConfig(model=net, labeled_bs=1, batch_size=2, dtype=torch.bfloat16, seed=9, replay=replay), DEV)
+        losses = []
+        for vol, lab, _ in batches:
+            out = tr.step(vol.to(DEV), lab.to(DEV))
+            losses.append([float(out[k]) for k in ("loss", "ce", "dice", "cons", "fecl", "uncl")])
+        assert (tr._rp is not None) == replay and tr.iter_num == 7
+        runs[replay] = (np.array(losses), tr.flat_p.clone(), tr.flat_t.clone(), tr.flat_m.clone())
+    np.testing.assert_allclose(runs[True][0], runs[False][0], rtol=1e-5, atol=1e-6)
+    for a, b in zip(runs[True][1:], runs[False][1:]):
+        assert float((a - b).abs().max()) <= 1e-6 * float(b.abs().max())
