@@ -27,6 +27,8 @@ SIGNATURES = {
     "dycon_pack_tcn": (I, [P, P, I, I, I, I, L, L, L, L, I, P]),
     "dycon_conv_gemm_workspace": (Z, [I, I, I, I, I, I, I, I, I]),
     "dycon_conv_gemm": (I, [P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, P, Z, P]),
+    "dycon_conv_gemm_splits": (I, [I, I, I, I, I, I, I, I, I]),
+    "dycon_conv_gemm_ex": (I, [P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, P, Z, I, P]),
     "dycon_conv_direct": (I, [P, I, P, P, P, I, I, I, I, I, I, I, I, I, P]),
     "dycon_conv_wgrad_workspace": (Z, [I, I, I, I, I, I, I]),
     "dycon_conv_wgrad": (I, [P, I, P, I, P, P, I, I, I, I, I, I, I, L, L, L, P, Z, P]),
@@ -35,6 +37,8 @@ SIGNATURES = {
     "dycon_norm_workspace": (Z, [I, L, I]),
     "dycon_norm_stats": (I, [P, I, I, L, I, I, F, P, P, P, F, P, Z, P]),
     "dycon_norm_fwd": (I, [P, P, I, I, L, I, I, F, P, P, P, I, P, P, P, P, F, P, Z, P]),
+    "dycon_norm_fwd_is_fused": (I, [I, L, I, I]),
+    "dycon_norm_fwd_slab": (I, [P, I, P, P, P, I, I, L, I, I, F, P, P, P, I, P, P, P]),
     "dycon_norm_apply": (I, [P, P, I, I, L, I, I, P, P, P, I, P, P, P]),
     "dycon_norm_bwd": (I, [P, I, P, P, I, I, L, I, I, P, P, P, I, P, P, P, P, Z, P]),
     "dycon_maxpool2_fwd": (I, [P, P, P, I, I, I, I, I, I, P]),

@@ -1660,7 +1660,7 @@ extern "C" int dycon_pack_batch(const dycon_pack_job_t* jobs_dev, int njobs, int
 
 template <typename T, int MODE, bool SC>
 static void launch_gemm(const void* x, const void* wf, const float* bias, void* y, int accumulate, int B, int Di, int Hi,
-                        int Wi, int Cin, int N, int Cout, float* workspace, dycon_stream_t stream) {
+                        int Wi, int Cin, int N, int Cout, float* workspace, int defer_finish, dycon_stream_t stream) {
     int Do, Ho, Wo;
     row_grid(MODE, Di, Hi, Wi, Do, Ho, Wo);
     const long long M = (long long)B * Do * Ho * Wo;
@@ -1673,7 +1673,7 @@ static void launch_gemm(const void* x, const void* wf, const float* bias, void* 
     conv_gemm_kernel<T, MODE, SC><<<grid, 256, 0, stream>>>((const T*)x, (const T*)wf, bias, (T*)y, B, Di, Hi, Wi, Cin, Do, Ho,
                                                             Wo, N, Cout, NT, nKC, accumulate, split ? workspace : nullptr,
                                                             sk.kc_per_split);
-    if (split) {
+    if (split && !defer_finish) {
         long long blocks = (M * N + 255) / 256;
         if (blocks > 2048) blocks = 2048;
         splitk_finish_kernel<T><<<(int)blocks, 256, 0, stream>>>(workspace, sk.splits, M * N, N, bias, (T*)y, accumulate);
@@ -1689,10 +1689,35 @@ extern "C" size_t dycon_conv_gemm_workspace(int dtype, int mode, int scatter, in
     return sk.splits > 1 ? (size_t)sk.splits * M * N * sizeof(float) : 0;
 }
 
+extern "C" int dycon_conv_gemm_splits(int dtype, int mode, int scatter, int B, int Di, int Hi, int Wi, int Cin, int N) {
+    int Do, Ho, Wo;
+    row_grid(mode, Di, Hi, Wi, Do, Ho, Wo);
+    const long long M = (long long)B * Do * Ho * Wo;
+    const SplitK sk = conv_tile_ok(dtype, mode, scatter, (long long)Di * Hi * Wi, Cin, N) ? conv_tile_plan(M, N, Cin)
+                                                                                       : splitk_plan(dtype, mode, scatter, M, N, Cin);
+    return sk.splits;
+}
+
+// defer_finish = 1 (split-K shapes with a workspace only): leave the partial slabs in `workspace` and do NOT launch the finish --
+// the caller completes the convolution with dycon_norm_fwd_slab (bias, ordered sum, rounding, norm in one launch).
+extern "C" int dycon_conv_gemm_ex(const void* x, const void* wfrag, const float* bias, void* y, int dtype, int mode,
+                                  int scatter, int accumulate, int B, int Di, int Hi, int Wi, int Cin, int N, int Cout,
+                                  float* workspace, size_t ws_bytes, int defer_finish, dycon_stream_t stream);
+
 extern "C" int dycon_conv_gemm(const void* x, const void* wfrag, const float* bias, void* y, int dtype, int mode,
                                int scatter, int accumulate, int B, int Di, int Hi, int Wi, int Cin, int N, int Cout,
                                float* workspace, size_t ws_bytes, dycon_stream_t stream) {
+    return dycon_conv_gemm_ex(x, wfrag, bias, y, dtype, mode, scatter, accumulate, B, Di, Hi, Wi, Cin, N, Cout, workspace, ws_bytes, 0,
+                              stream);
+}
+
+extern "C" int dycon_conv_gemm_ex(const void* x, const void* wfrag, const float* bias, void* y, int dtype, int mode,
+                                  int scatter, int accumulate, int B, int Di, int Hi, int Wi, int Cin, int N, int Cout,
+                                  float* workspace, size_t ws_bytes, int defer_finish, dycon_stream_t stream) {
     DYCON_REQUIRE(x && wfrag && y, "conv_gemm: null pointer");
+    DYCON_REQUIRE(!defer_finish || (!accumulate && workspace && dycon_conv_gemm_splits(dtype, mode, scatter, B, Di, Hi, Wi, Cin, N) > 1 &&
+                                    ws_bytes >= dycon_conv_gemm_workspace(dtype, mode, scatter, B, Di, Hi, Wi, Cin, N)),
+                  "conv_gemm: defer_finish needs a split-K shape, its workspace and no accumulation");
     DYCON_REQUIRE(B > 0 && Di > 0 && Hi > 0 && Wi > 0 && Cin > 0 && N > 0 && Cout > 0, "conv_gemm: bad shape");
     DYCON_REQUIRE(mode >= 0 && mode <= 2, "conv_gemm: bad mode %d", mode);
     const bool first_layer_lds = dtype == DYCON_BF16 && mode == DYCON_CONV_K3 && !scatter && Cin == 1 &&
@@ -1745,7 +1770,7 @@ extern "C" int dycon_conv_gemm(const void* x, const void* wfrag, const float* bi
         conv_k3_tile_kernel<<<grid, 256, 0, stream>>>((const bf16*)x, (const bf16*)wfrag, bias, (bf16*)y, split ? workspace : nullptr, B,
                                                       Di, Hi, Wi, Cin, N, NT, nKC, sk.kc_per_split, accumulate);
         DYCON_LAUNCH_CHECK();
-        if (split) {
+        if (split && !defer_finish) {
             long long blocks = (M * N + 255) / 256;
             if (blocks > 2048) blocks = 2048;
             splitk_finish_kernel<bf16><<<(int)blocks, 256, 0, stream>>>(workspace, sk.splits, M * N, N, bias, (bf16*)y, accumulate);
@@ -1756,10 +1781,10 @@ extern "C" int dycon_conv_gemm(const void* x, const void* wfrag, const float* bi
     // split-K only when the caller provides the slab workspace (NULL -> single pass, same result up to fp32 summation order)
     float* ws = (workspace && ws_bytes >= dycon_conv_gemm_workspace(dtype, mode, scatter, B, Di, Hi, Wi, Cin, N)) ? workspace : nullptr;
     DYCON_DISPATCH(dtype, {
-        if (scatter) launch_gemm<T, DYCON_CONV_1X1, true>(x, wfrag, bias, y, accumulate, B, Di, Hi, Wi, Cin, N, Cout, ws, stream);
-        else if (mode == DYCON_CONV_K3) launch_gemm<T, DYCON_CONV_K3, false>(x, wfrag, bias, y, accumulate, B, Di, Hi, Wi, Cin, N, Cout, ws, stream);
-        else if (mode == DYCON_CONV_K2S2) launch_gemm<T, DYCON_CONV_K2S2, false>(x, wfrag, bias, y, accumulate, B, Di, Hi, Wi, Cin, N, Cout, ws, stream);
-        else launch_gemm<T, DYCON_CONV_1X1, false>(x, wfrag, bias, y, accumulate, B, Di, Hi, Wi, Cin, N, Cout, ws, stream);
+        if (scatter) launch_gemm<T, DYCON_CONV_1X1, true>(x, wfrag, bias, y, accumulate, B, Di, Hi, Wi, Cin, N, Cout, ws, defer_finish, stream);
+        else if (mode == DYCON_CONV_K3) launch_gemm<T, DYCON_CONV_K3, false>(x, wfrag, bias, y, accumulate, B, Di, Hi, Wi, Cin, N, Cout, ws, defer_finish, stream);
+        else if (mode == DYCON_CONV_K2S2) launch_gemm<T, DYCON_CONV_K2S2, false>(x, wfrag, bias, y, accumulate, B, Di, Hi, Wi, Cin, N, Cout, ws, defer_finish, stream);
+        else launch_gemm<T, DYCON_CONV_1X1, false>(x, wfrag, bias, y, accumulate, B, Di, Hi, Wi, Cin, N, Cout, ws, defer_finish, stream);
     });
     DYCON_LAUNCH_CHECK();
     return DYCON_OK;

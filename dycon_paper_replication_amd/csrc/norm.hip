@@ -266,24 +266,47 @@ __device__ __forceinline__ void block_reduce_vec(float (&v)[NV], float* sm /* [4
     for (int k = 0; k < NV; ++k) v[k] = sm[k] + sm[NV + k] + sm[2 * NV + k] + sm[3 * NV + k];
 }
 
-template <typename T, int SPAN, int CPG>
-__global__ __launch_bounds__(256) void norm_fused_fwd_kernel(const T* __restrict__ X, T* __restrict__ Y, long long V, int C, int G,
+// SLAB = true: x does not exist yet -- it is the ordered sum of the split-K partial slabs of the convolution that feeds this norm
+// (conv_k3_tile_kernel / conv_gemm_kernel, fp32 [split][row][channel]) plus the bias.  The statistics pass forms it (the same
+// summation order as splitk_finish_kernel), rounds it to T, WRITES it to X (the backward needs the pre-norm tensor) and takes the
+// statistics of the rounded values: bit-identical to finish launch + norm launch, with one launch less on the critical chain.
+template <typename T, int SPAN, int CPG, bool SLAB>
+__global__ __launch_bounds__(256) void norm_fused_fwd_kernel(T* __restrict__ X, T* __restrict__ Y, long long V, int C, int G,
                                                              float eps, float* __restrict__ stats, const float* __restrict__ gamma,
                                                              const float* __restrict__ beta, int relu, const T* __restrict__ skip,
                                                              const float* __restrict__ chan_scale, float* running_mean,
-                                                             float* running_var, float momentum) {
+                                                             float* running_var, float momentum, const float* __restrict__ slab,
+                                                             int splits, long long MN, const float* __restrict__ cbias) {
     constexpr int VN = Vec16<T>::N, NVEC = SPAN / VN;
     __shared__ float sm[4 * 2 * SPAN];
     constexpr int cpg = CPG;
     const int n = blockIdx.y, c0 = blockIdx.x * SPAN;
-    const T* xp = X + (long long)n * V * C + c0;
+    T* xp = X + (long long)n * V * C + c0;
     float acc[2 * SPAN];
 #pragma unroll
     for (int k = 0; k < 2 * SPAN; ++k) acc[k] = 0.f;
     for (long long v = threadIdx.x; v < V; v += 256) {
 #pragma unroll
         for (int q = 0; q < NVEC; ++q) {
-            const Vec16<T> x = ld16(xp + v * C + q * VN);
+            Vec16<T> x;
+            if (SLAB) {
+                const long long off = ((long long)n * V + v) * C + c0 + q * VN;
+                float f[VN];
+#pragma unroll
+                for (int k = 0; k < VN; ++k) f[k] = cbias ? cbias[c0 + q * VN + k] : 0.f;
+                for (int z = 0; z < splits; ++z) {
+#pragma unroll
+                    for (int k = 0; k < VN; k += 4) {
+                        const float4 p = *reinterpret_cast<const float4*>(slab + (long long)z * MN + off + k);
+                        f[k] += p.x; f[k + 1] += p.y; f[k + 2] += p.z; f[k + 3] += p.w;
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < VN; ++k) x.set(k, f[k]);
+                st16(xp + v * C + q * VN, x);
+            } else {
+                x = ld16(xp + v * C + q * VN);
+            }
 #pragma unroll
             for (int k = 0; k < VN; ++k) { const float f = x.get(k); acc[q * VN + k] += f; acc[SPAN + q * VN + k] += f * f; }
         }
@@ -451,6 +474,30 @@ static int norm_check(const char* who, int dtype, int Nb, long long V, int C, in
     return DYCON_OK;
 }
 
+extern "C" int dycon_norm_fwd_is_fused(int dtype, long long V, int C, int G) {
+    return (G > 0 && C % G == 0 && norm_fused_ok(dtype, V, C, G)) ? 1 : 0;
+}
+
+// One-launch norm of the small levels fed directly by the split-K slabs of the producing convolution (bf16 storage): forms
+// x = bias + sum_z slab[z] (written to x_out for the backward), its statistics, and y.  Replaces splitk_finish + dycon_norm_fwd.
+extern "C" int dycon_norm_fwd_slab(const float* slab, int splits, const float* conv_bias, void* x_out, void* y, int dtype, int Nb,
+                                   long long V, int C, int G, float eps, float* stats, const float* gamma, const float* beta,
+                                   int relu, const void* skip, const float* chan_scale, dycon_stream_t stream) {
+    DYCON_REQUIRE(slab && x_out && y && stats && splits > 0, "norm_fwd_slab: bad arguments");
+    DYCON_REQUIRE(dtype == DYCON_BF16, "norm_fwd_slab: bf16 storage only");
+    if (int e = norm_check("norm_fwd_slab", dtype, Nb, V, C, G)) return e;
+    DYCON_REQUIRE(norm_fused_ok(dtype, V, C, G), "norm_fwd_slab: this shape is not served by the one-launch norm (ask dycon_norm_fwd_is_fused)");
+    const int cpg = C / G, span = cpg > 8 ? cpg : 8;
+    const long long MN = (long long)Nb * V * C;
+    dim3 grid(C / span, Nb);
+#define DYCON_NFS(SP, CP) norm_fused_fwd_kernel<bf16, SP, CP, true><<<grid, 256, 0, stream>>>((bf16*)x_out, (bf16*)y, V, C, G, eps, stats, gamma, beta, relu, (const bf16*)skip, chan_scale, nullptr, nullptr, 0.f, slab, splits, MN, conv_bias)
+    if (cpg == 1) DYCON_NFS(8, 1); else if (cpg == 2) DYCON_NFS(8, 2); else if (cpg == 4) DYCON_NFS(8, 4);
+    else if (cpg == 8) DYCON_NFS(8, 8); else DYCON_NFS(16, 16);
+#undef DYCON_NFS
+    DYCON_LAUNCH_CHECK();
+    return DYCON_OK;
+}
+
 extern "C" int dycon_norm_stats(const void* x, int dtype, int Nb, long long V, int C, int G, float eps, float* stats,
                                 float* running_mean, float* running_var, float momentum, float* workspace, size_t ws_bytes,
                                 dycon_stream_t stream) {
@@ -480,7 +527,7 @@ extern "C" int dycon_norm_fwd(const void* x, void* y, int dtype, int Nb, long lo
         const int VN = dtype == DYCON_BF16 ? 8 : 4, cpg = C / G;
         const int span = cpg > VN ? cpg : VN;
         dim3 grid(C / span, Nb);
-#define DYCON_NF(TT, SP, CP) norm_fused_fwd_kernel<TT, SP, CP><<<grid, 256, 0, stream>>>((const TT*)x, (TT*)y, V, C, G, eps, stats, gamma, beta, relu, (const TT*)skip, chan_scale, running_mean, running_var, momentum)
+#define DYCON_NF(TT, SP, CP) norm_fused_fwd_kernel<TT, SP, CP, false><<<grid, 256, 0, stream>>>((TT*)const_cast<void*>(x), (TT*)y, V, C, G, eps, stats, gamma, beta, relu, (const TT*)skip, chan_scale, running_mean, running_var, momentum, nullptr, 0, 0, nullptr)
         if (dtype == DYCON_BF16) {
             if (cpg == 1) DYCON_NF(bf16, 8, 1); else if (cpg == 2) DYCON_NF(bf16, 8, 2); else if (cpg == 4) DYCON_NF(bf16, 8, 4);
             else if (cpg == 8) DYCON_NF(bf16, 8, 8); else DYCON_NF(bf16, 16, 16);

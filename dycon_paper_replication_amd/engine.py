@@ -148,6 +148,11 @@ class Engine:
         self.Gs = {}
         self._head_range = (0, 0)
         self._wws = {}               # per-layer workspaces of the weight-gradient launches
+        # split-K finish of a conv fused into the one-launch norm that follows (small levels, bf16): bit-identical and one launch
+        # less, but measured SLOWER (5.8 -> 6.1 ms/step): the norm's workgroups own 8-16 channels of one sample, so they read the
+        # fp32 slabs in 32-byte pieces at a C*4-byte stride where splitk_finish streams them fully coalesced.  Off by default.
+        self.fuse_finish = False
+        self._deferred = {}
         self.tape = []
         self.G = {}
 
@@ -243,7 +248,7 @@ class Engine:
         self._put(t, g if cur is None else ops.add(cur, g))
 
     # ---------------------------------------------------------------- conv layers
-    def _conv(self, name, x, kind, need_gx=True, out_dtype=None):
+    def _conv(self, name, x, kind, need_gx=True, out_dtype=None, norm_groups=0):
         """kind: k3 | k2s2 | deconv | 1x1.  Weight layouts as in torch (Conv3d: (Co,Ci,k..); ConvTranspose3d: (Ci,Co,k..))."""
         w, b = self.p[name + ".weight"], self.p[name + ".bias"]
         dtype = self.dtype
@@ -273,7 +278,15 @@ class Engine:
             y = ops.conv_gemm(x, wf, b, mode, Cout, Cout)
         else:
             wf = self._pk((name, "f"), "frag", w, T, Cin, Cout, Cout, 1, T, 0, Cin * T)
-            y = ops.conv_gemm(x, wf, b, mode, Cout, Cout)
+            # a GroupNorm / InstanceNorm of the one-launch kind follows (norm_groups > 0): leave a split-K finish to it
+            Vo = (x.shape[1] * x.shape[2] * x.shape[3]) // (8 if kind == "k2s2" else 1)
+            if (norm_groups and self.fuse_finish and dtype == torch.bfloat16 and out_dtype == dtype
+                    and ops.norm_fwd_is_fused(x, Vo, Cout, norm_groups)):
+                y, dc = ops.conv_gemm(x, wf, b, mode, Cout, Cout, defer_finish=True)
+                if dc is not None:
+                    self._deferred[id(y)] = dc
+            else:
+                y = ops.conv_gemm(x, wf, b, mode, Cout, Cout)
 
         if self.recording:
             def wgrad(gy):
@@ -355,6 +368,8 @@ class Engine:
             # eval-mode BatchNorm (ISLES teacher, train_DyCON_ISLES22.py:114): running statistics
             stats = torch.stack([rm, torch.rsqrt(rv + 1e-5)], 1).reshape(-1).contiguous()
             y = ops.norm_apply(z, stats, Nb, V, C, G, gamma, beta, relu, skip, chan_scale=chan_scale)
+        elif id(z) in self._deferred:     # z is still split-K slabs: bias + ordered sum + rounding + norm in ONE launch
+            y, stats = ops.norm_fwd_slab(z, self._deferred.pop(id(z)), Nb, V, C, G, gamma, beta, relu, skip, chan_scale)
         else:
             upd = kind == "bn" and training and self.update_bn
             y, stats = ops.norm_fwd(z, Nb, V, C, G, gamma, beta, relu, skip, chan_scale, 1e-5, rm if upd else None,
@@ -449,9 +464,12 @@ class Engine:
     def _vnet(self, x, training):
         nk = "gn" if self.normalization == "groupnorm" else "in"
 
+        def ngroups(t, conv):       # groups of the norm that follows this conv: GroupNorm(16, C) or InstanceNorm (G = C)
+            return 16 if nk == "gn" else self.p[conv + ".weight"].shape[0]
+
         def block(name, t, n, first=False, drop=None):
             for i in range(n):
-                t = self._conv(f"{name}.conv.{3 * i}", t, "k3", need_gx=not (first and i == 0))
+                t = self._conv(f"{name}.conv.{3 * i}", t, "k3", need_gx=not (first and i == 0), norm_groups=ngroups(t, f"{name}.conv.{3 * i}"))
                 cs = None
                 if drop is not None and i == n - 1:
                     cs = self._channel_scale(t.shape[0], t.shape[-1], drop[0], 0.5, drop[1], t.device)
@@ -459,7 +477,7 @@ class Engine:
             return t
 
         def down(name, t):
-            return self._norm(f"{name}.conv.1", self._conv(f"{name}.conv.0", t, "k2s2"), nk)
+            return self._norm(f"{name}.conv.1", self._conv(f"{name}.conv.0", t, "k2s2", norm_groups=ngroups(t, f"{name}.conv.0")), nk)
 
         def up(name, t, skip):
             return self._norm(f"{name}.conv.1", self._conv(f"{name}.conv.0", t, "deconv"), nk, skip=skip)
@@ -482,8 +500,9 @@ class Engine:
     # ---------------------------------------------------------------- U-Net
     def _unet(self, x, training, want_sdf):
         def uconv(prefix, t, first=False):
-            t = self._norm(None, self._conv(prefix + ".conv1.0", t, "k3", need_gx=not first), "in")
-            return self._norm(None, self._conv(prefix + ".conv2.0", t, "k3"), "in")
+            c1, c2 = self.p[prefix + ".conv1.0.weight"].shape[0], self.p[prefix + ".conv2.0.weight"].shape[0]
+            t = self._norm(None, self._conv(prefix + ".conv1.0", t, "k3", need_gx=not first, norm_groups=c1), "in")
+            return self._norm(None, self._conv(prefix + ".conv2.0", t, "k3", norm_groups=c2), "in")
 
         def pool(t):
             y, idx = ops.maxpool2_fwd(t)
@@ -537,6 +556,7 @@ class Engine:
         self.update_bn = update_bn
         self.dropout = dropout or DropoutSpec("off")
         self.tape, self.G = [], {}
+        self._deferred = {}
         if x.dtype != self.dtype:
             x = ops.cast(x, self.dtype)
         if self.net_type == "vnet":

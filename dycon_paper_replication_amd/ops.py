@@ -195,8 +195,31 @@ def conv_uses_lds(x, Cin, Cout):
 
 
 # ------------------------------------------------------------------ conv family
-def conv_gemm(x, wfrag, bias, mode, N, Cout, scatter=False, out=None, accumulate=False):
+class DeferredConv:
+    """A split-K convolution whose finish was left to the norm that follows (conv_gemm(defer_finish=True))."""
+    __slots__ = ("ws", "splits", "bias")
+
+    def __init__(self, ws, splits, bias):
+        self.ws, self.splits, self.bias = ws, splits, bias
+
+
+def conv_gemm(x, wfrag, bias, mode, N, Cout, scatter=False, out=None, accumulate=False, defer_finish=False):
+    """defer_finish: on split-K shapes return (out, DeferredConv): `out` is allocated but NOT written; norm_fwd_slab completes it."""
     B, D, H, W, Cin = x.shape
+    if defer_finish:
+        assert out is None and not accumulate and not scatter
+        splits = query("dycon_conv_gemm_splits", dt(x), mode, 0, B, D, H, W, Cin, N)
+        if splits <= 1:
+            return conv_gemm(x, wfrag, bias, mode, N, Cout), None
+        shape = (B, D // 2, H // 2, W // 2, N) if mode == CONV_K2S2 else (B, D, H, W, N)
+        out = torch.empty(shape, dtype=x.dtype, device=x.device)
+        nws = query("dycon_conv_gemm_workspace", dt(x), mode, 0, B, D, H, W, Cin, N)
+        ws = _ws(nws, x)
+        rn = "conv_k3_tile" if (mode == CONV_K3 and Cin % 32 == 0 and Cin >= 64 and N % 128 == 0) else "conv_gemm_splitk"
+        taps = {CONV_K3: 27, CONV_K2S2: 8, CONV_1X1: 1}[mode]
+        with _Region(rn, (x.numel() + out.numel()) * _es(x) + taps * Cin * N * _es(x), 2 * (out.numel() // Cout) * taps * Cin * N):
+            call("dycon_conv_gemm_ex", _p(x), _p(wfrag), _p(bias), _p(out), dt(x), mode, 0, 0, B, D, H, W, Cin, N, Cout, _p(ws), nws, 1, _s())
+        return out, DeferredConv(ws, splits, bias)
     if out is None:
         assert not accumulate
         if scatter:
@@ -295,6 +318,20 @@ def norm_fwd(x, Nb, V, C, G, gamma=None, beta=None, relu=True, skip=None, chan_s
     with _Region("norm_fwd", x.numel() * _es(x) * (4 if skip is not None else 3), 6 * x.numel()):
         call("dycon_norm_fwd", _p(x), _p(y), dt(x), Nb, V, C, G, eps, _p(stats), _p(gamma), _p(beta), int(relu), _p(skip),
              _p(chan_scale), _p(running_mean), _p(running_var), momentum, _p(ws), ws.numel() * 4, _s())
+    return y, stats
+
+
+def norm_fwd_is_fused(x, V, C, G):
+    return bool(query("dycon_norm_fwd_is_fused", dt(x), V, C, G))
+
+
+def norm_fwd_slab(x_out, dc: DeferredConv, Nb, V, C, G, gamma=None, beta=None, relu=True, skip=None, chan_scale=None, eps=1e-5):
+    """Complete a deferred split-K convolution (writes x_out) and normalise it in the same launch.  Returns (y, stats)."""
+    y = torch.empty_like(x_out)
+    stats = torch.empty(Nb * G * 2, dtype=torch.float32, device=x_out.device)
+    with _Region("norm_fwd", x_out.numel() * _es(x_out) * (4 if skip is not None else 3), 6 * x_out.numel()):
+        call("dycon_norm_fwd_slab", _p(dc.ws), dc.splits, _p(dc.bias), _p(x_out), _p(y), dt(x_out), Nb, V, C, G, eps, _p(stats),
+             _p(gamma), _p(beta), int(relu), _p(skip), _p(chan_scale), _s())
     return y, stats
 
 

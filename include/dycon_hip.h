@@ -85,6 +85,15 @@ size_t dycon_conv_gemm_workspace(int dtype, int mode, int scatter, int B, int Di
 int dycon_conv_gemm(const void* x, const void* wfrag, const float* bias, void* y, int dtype,
                     int mode, int scatter, int accumulate, int B, int Di, int Hi, int Wi, int Cin,
                     int N, int Cout, float* workspace, size_t ws_bytes, dycon_stream_t stream);
+/* dycon_conv_gemm with defer_finish: on a split-K shape (dycon_conv_gemm_splits() > 1, workspace given, no accumulation) the
+ * partial slabs stay in `workspace` ([split][row][N] fp32) and no finish is launched; the convolution is completed by
+ * dycon_norm_fwd_slab, which fuses bias + ordered slab sum + rounding with the GroupNorm / InstanceNorm that follows
+ * (VNet.py:16-23 at the 12^3 / 6^3 levels): one launch less on the step's critical chain, bit-identical results. */
+int dycon_conv_gemm_splits(int dtype, int mode, int scatter, int B, int Di, int Hi, int Wi, int Cin, int N);
+int dycon_conv_gemm_ex(const void* x, const void* wfrag, const float* bias, void* y, int dtype,
+                       int mode, int scatter, int accumulate, int B, int Di, int Hi, int Wi, int Cin,
+                       int N, int Cout, float* workspace, size_t ws_bytes, int defer_finish,
+                       dycon_stream_t stream);
 /* skinny channels (first layer 1->16, 1x1 heads 16->2 and their data-gradient 2->16):
  * w_tcn is fp32 [T][Cin][N]; x and y may have different dtypes (bf16 features, fp32 logits). */
 int dycon_conv_direct(const void* x, int x_dtype, const float* w_tcn, const float* bias, void* y,
@@ -121,6 +130,14 @@ int dycon_norm_fwd(const void* x, void* y, int dtype, int Nb, long long V, int C
                    float* stats, const float* gamma, const float* beta, int relu, const void* skip,
                    const float* chan_scale, float* running_mean, float* running_var, float momentum,
                    float* workspace, size_t ws_bytes, dycon_stream_t stream);
+/* 1 when dycon_norm_fwd serves this shape with its one-launch kernel (V <= 2048, whole groups per workgroup) */
+int dycon_norm_fwd_is_fused(int dtype, long long V, int C, int G);
+/* One-launch norm fed by the split-K slabs of the producing convolution (bf16 storage, shapes with dycon_norm_fwd_is_fused):
+ * x_out = bf16(conv_bias + sum_z slab[z]) (kept for the backward), stats, y -- see dycon_conv_gemm_ex. */
+int dycon_norm_fwd_slab(const float* slab, int splits, const float* conv_bias, void* x_out, void* y,
+                        int dtype, int Nb, long long V, int C, int G, float eps, float* stats,
+                        const float* gamma, const float* beta, int relu, const void* skip,
+                        const float* chan_scale, dycon_stream_t stream);
 /* y = act(gamma*(x-mean)*rstd + beta) * chan_scale[n,c] + skip ; gamma/beta/skip/chan_scale may be
  * NULL; y may alias x.  chan_scale (Nb, C) = keep/(1-p) fuses nn.Dropout3d (VNet.py:177,196,226). */
 int dycon_norm_apply(const void* x, void* y, int dtype, int Nb, long long V, int C, int G,

@@ -193,6 +193,39 @@ def test_norm(kind, C, mode):
         close(nc(gz2), zr.grad, 2e-3, 2e-4, "gz from y")
 
 
+@pytest.mark.parametrize("kind,cin,cout,sp,nk", [("k3", 128, 128, (6, 6, 6), "gn"), ("k3", 128, 256, (5, 6, 4), "gn"), ("k3", 256, 256, (6, 6, 6), "in"),
+                                                 ("k2s2", 64, 128, (12, 12, 12), "gn"), ("k3", 64, 64, (6, 6, 6), "gn")])
+def test_split_k_finish_fused_into_norm(kind, cin, cout, sp, nk):
+    """Small levels, bf16: the split-K finish of the convolution (bias + ordered slab sum + rounding) done by the one-launch norm
+    that follows (dycon_conv_gemm_ex defer_finish + dycon_norm_fwd_slab) must reproduce finish launch + norm launch bit for bit:
+    pre-norm tensor (kept for the backward), statistics, output, and the gradients of a backward through both."""
+    rng = np.random.default_rng(cin + cout)
+    B = 3
+    k = 3 if kind == "k3" else 2
+    params = {"l.weight": T((rng.standard_normal((cout, cin, k, k, k)) * 0.05).astype(np.float32)),
+              "l.bias": T((rng.standard_normal(cout) * 0.3).astype(np.float32)),
+              "n.weight": T((1 + 0.2 * rng.standard_normal(cout)).astype(np.float32)),
+              "n.bias": T((0.2 * rng.standard_normal(cout)).astype(np.float32))}
+    xd = nd(T(rng.standard_normal((B, cin) + sp).astype(np.float32)), torch.bfloat16)
+    G = 16 if nk == "gn" else cout
+    res = []
+    for fuse in (False, True):
+        e = mini_engine(params, torch.bfloat16)
+        e.fuse_finish = fuse
+        z = e._conv("l", xd, kind, norm_groups=G)
+        deferred = id(z) in e._deferred
+        y = e._norm("n" if nk == "gn" else None, z, nk)
+        gy = torch.ones_like(y) * 0.5
+        e.G[id(y)] = gy
+        for fn in reversed(e.tape):
+            fn()
+        res.append((deferred, z.clone(), y.clone(), e.G[id(xd)].clone(), e.g["l.weight"].clone()))
+    assert res[1][0] or ops.query("dycon_conv_gemm_splits", 1, 1 if kind == "k3" else 2, 0, B, *sp, cin, cout) <= 1
+    assert not res[0][0]
+    for a, b in zip(res[0][1:], res[1][1:]):
+        assert torch.equal(a, b)
+
+
 def test_golden_pool_trilinear():
     g = load_golden("unet_layers")
     x = T(g["maxpool.x"])
