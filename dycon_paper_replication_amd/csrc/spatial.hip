@@ -158,7 +158,7 @@ template <typename T>
 __global__ void trilinear_bwd_kernel(const T* __restrict__ GY, T* __restrict__ GX, int B, int Di, int Hi, int Wi, int Do, int Ho,
                                      int Wo, int C, int ldy, int coff, int align, long long total) {
     constexpr int VN = Vec16<T>::N;
-    constexpr int MAXO = 12;                       // contributing outputs per axis (scale <= 4)
+    constexpr int MAXO = 18;                       // candidate outputs per axis held in registers (tri_range: 9 at scale 2, 18 at 4.5)
     const int CG = C / VN;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         const int cg = (int)(i % CG);
@@ -174,18 +174,36 @@ __global__ void trilinear_bwd_kernel(const T* __restrict__ GY, T* __restrict__ G
         float acc[VN];
 #pragma unroll
         for (int k = 0; k < VN; ++k) acc[k] = 0.f;
+        // x-axis weights of the candidate outputs once per thread (statically indexed registers): evaluated inside the loop nest they
+        // were recomputed for every (oz, oy) pair -- 144 of the 189 coordinate computations per thread at scale 2
+        float wxs[MAXO];
+        const bool xfit = xh - xl < MAXO;
+#pragma unroll
+        for (int k = 0; k < MAXO; ++k) wxs[k] = (xfit && xl + k <= xh) ? tri_w(xl + k, x, Wi, Wo, align) : 0.f;
         for (int oz = zl; oz <= zh; ++oz) {
             const float wz = tri_w(oz, z, Di, Do, align);
             if (wz == 0.f) continue;
             for (int oy = yl; oy <= yh; ++oy) {
                 const float wzy = wz * tri_w(oy, y, Hi, Ho, align);
                 if (wzy == 0.f) continue;
-                for (int ox = xl; ox <= xh; ++ox) {
-                    const float w = wzy * tri_w(ox, x, Wi, Wo, align);
-                    if (w == 0.f) continue;
-                    const Vec16<T> g = ld16(GY + ((((long long)b * Do + oz) * Ho + oy) * Wo + ox) * ldy + coff + cg * VN);
+                const T* row = GY + ((((long long)b * Do + oz) * Ho + oy) * Wo + xl) * ldy + coff + cg * VN;
+                if (xfit) {
 #pragma unroll
-                    for (int k = 0; k < VN; ++k) acc[k] += w * g.get(k);
+                    for (int k = 0; k < MAXO; ++k) {
+                        const float w = wzy * wxs[k];
+                        if (w == 0.f) continue;
+                        const Vec16<T> g = ld16(row + (long long)k * ldy);
+#pragma unroll
+                        for (int e = 0; e < VN; ++e) acc[e] += w * g.get(e);
+                    }
+                } else {      // very large scale factors: evaluate in place
+                    for (int ox = xl; ox <= xh; ++ox) {
+                        const float w = wzy * tri_w(ox, x, Wi, Wo, align);
+                        if (w == 0.f) continue;
+                        const Vec16<T> g = ld16(row + (long long)(ox - xl) * ldy);
+#pragma unroll
+                        for (int e = 0; e < VN; ++e) acc[e] += w * g.get(e);
+                    }
                 }
             }
         }
@@ -194,7 +212,6 @@ __global__ void trilinear_bwd_kernel(const T* __restrict__ GY, T* __restrict__ G
         for (int k = 0; k < VN; ++k) o.set(k, acc[k]);
         st16(GX + i * VN, o);
     }
-    (void)MAXO;
 }
 
 // ------------------------------------------------------------------------------------------------
