@@ -211,7 +211,9 @@ class DyconTrainer:
         The tensors in the returned dict are then the recorded step's buffers: valid until the next step."""
         c = self.cfg
         sig = None
-        if c.replay and noise is None and s_drop is None and t_drop is None and ops.PROFILER is None:
+        # (single-process runs only: with a process group the step contains torch.distributed collectives, whose replay as
+        # recorded closures is not validated on RCCL -- the gloo rehearsal ran 8x slower -- so DDP ranks stay on the eager path)
+        if c.replay and self.world == 1 and noise is None and s_drop is None and t_drop is None and ops.PROFILER is None:
             sig = (tuple(volume.shape), volume.dtype, tuple(label.shape), label.dtype, torch.cuda.current_stream().cuda_stream)
         with ops.on_stream(None):
             if sig is None:
