@@ -132,6 +132,22 @@ def test_vnet_isles_geometry_vs_oracle():
     np.testing.assert_allclose(feats.cpu().permute(0, 4, 1, 2, 3).numpy(), fe_ref.numpy(), rtol=3e-4, atol=3e-4)
 
 
+@pytest.mark.parametrize("kind", ["vnet", "unet"])
+def test_pancreas_geometry_vs_oracle(kind):
+    """BASELINE config 3: the reference hard-codes (112, 112, 96) patches for Pancreas (train_DyCON_Pancreas.py:99): 7 x 7 x 6 at the
+    bottleneck, feature_scaler 2 -> 14 x 14 x 12 = 2352 embeddings.  fp32 storage vs the oracle, forward only (B = 1), both nets."""
+    eng, p_all = build(kind, 5)
+    torch.manual_seed(2)
+    x = torch.randn(1, 1, 112, 112, 96)
+    fwd = ON.vnet_forward if kind == "vnet" else ON.unet_forward
+    with torch.no_grad():
+        _, lo_ref, fe_ref = fwd(x, p_all, scale_factor=2)
+    logits, feats, _ = eng.forward(x.permute(0, 2, 3, 4, 1).contiguous().to(DEV), record=False)
+    assert tuple(feats.shape) == (1, 14, 14, 12, 256)
+    np.testing.assert_allclose(logits.cpu().permute(0, 4, 1, 2, 3).numpy(), lo_ref.numpy(), rtol=3e-4, atol=3e-4)
+    np.testing.assert_allclose(feats.cpu().permute(0, 4, 1, 2, 3).numpy(), fe_ref.numpy(), rtol=3e-4, atol=3e-4)
+
+
 def test_bf16_step_gradient_tracks_fp32_isles_geometry():
     """One full DyCON step at 112x112x80 (feature_scaler 4, ISLES variants: multi-class Dice, eval-mode teacher) in bf16 and
     fp32 storage from the same state: the flat gradient arenas agree in direction and size."""
