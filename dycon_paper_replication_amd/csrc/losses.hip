@@ -605,7 +605,9 @@ __global__ __launch_bounds__(256) void fecl_kernel(const T* __restrict__ F, cons
                     put_weight(Tt, (16 * wave + 4 * kg + i) * tstride + 16 * j + r, tv);
                 }
             }
-            __syncthreads();
+            // rows 16*wave .. 16*wave+15 of the pair-weight tile are written AND read by this wave only (LDS operations of one wave
+            // execute in order): no workgroup barrier between the epilogue and the gradient GEMM
+            __builtin_amdgcn_wave_barrier();
             weight_gemm<MAXNT>(Tt, tstride, Fj, stride, ntile, wave, lane, gacc);
         }
 
@@ -632,7 +634,7 @@ __global__ __launch_bounds__(256) void fecl_kernel(const T* __restrict__ F, cons
                 }
             }
             if (PASS == 4) {
-                __syncthreads();
+                __builtin_amdgcn_wave_barrier();
                 weight_gemm<MAXNT>(Tt, tstride, Fj, stride, ntile, wave, lane, gacc);
             }
         }
