@@ -58,6 +58,12 @@ SIGNATURES = {
     "dycon_seg_losses_bwd": (I, [P, P, P, I, I, I, L, F, P, P, I, P, P]),
     "dycon_seg_losses_finalize": (I, [P, I, I, L, F, P, P]),
     "dycon_step_loss": (I, [P, P, F, F, F, I, I, P, P, P]),
+    "dycon_softmax_mse_fwd": (I, [P, P, P, L, I, L, I, P]),
+    "dycon_softmax_mse_bwd": (I, [P, P, P, P, L, I, L, I, P]),
+    "dycon_softmax_kl_fwd": (I, [P, P, L, I, L, I, P, P, P]),
+    "dycon_softmax_kl_bwd": (I, [P, P, L, I, L, I, I, P, P, P]),
+    "dycon_dice_fwd": (I, [P, P, I, I, L, I, L, I, P, F, P, P, P]),
+    "dycon_dice_bwd": (I, [P, P, I, I, L, I, L, I, P, F, P, P, P, P]),
     "dycon_l2norm_fwd": (I, [P, P, P, I, L, I, F, P]),
     "dycon_l2norm_bwd": (I, [P, P, P, P, I, L, I, F, P]),
     "dycon_mask_pool": (I, [P, I, P, I, I, I, I, I, I, I, P]),
@@ -74,6 +80,11 @@ SIGNATURES = {
     "dycon_binary_overlap": (I, [P, P, I, L, P, P]),
     "dycon_batch_overlap": (I, [P, P, I, I, L, P, P]),
 }
+
+
+class View(C.Structure):
+    """dycon_view_t: a strided (n, C, V) fp32 view (element strides)."""
+    _fields_ = [("p", P), ("sn", L), ("sc", L), ("sv", L)]
 
 
 class DyconLibraryError(RuntimeError):

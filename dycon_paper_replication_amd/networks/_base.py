@@ -49,6 +49,7 @@ class _NetFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, net, *params):
         eng = net._engine()
+        eng.repack()                   # all stale packs in one launch (no-op when nothing changed)
         record = any(ctx.needs_input_grad[2:])
         logits, feats, sdf = eng.forward(to_ndhwc(x), training=net.training, record=record, dropout=net._dropout_spec(),
                                          update_bn=net.training, want_sdf=True)
@@ -106,6 +107,7 @@ class HipSegNet(nn.Module):
             _register(self, name, t, buffer=True)
         self._eng = None
         self._eng_key = None
+        self.weights_static = False    # True: parameters only change through version-counted in-place ops (see _engine)
         self._drop_calls = 0
         self._drop_seed = int(torch.initial_seed() & 0x7FFFFFFFFFFFFFFF)
 
@@ -132,8 +134,12 @@ class HipSegNet(nn.Module):
             self._eng = Engine(self.net_type, params, None, bufs, self.compute_dtype, self.scale_factor, self.normalization)
             self._eng_key = key
             self._ver = None
+        # Packed operands must follow the parameters.  optimizer.step() / load_state_dict bump the tensors' version counters, but
+        # the reference's EMA writes through `.data` (train_DyCON_BraTS19.py:163-164), which does NOT: so unless the caller
+        # declared the weights frozen (`weights_static`, the sliding-window evaluator), every forward refreshes all packs -- one
+        # batched launch (Engine.repack) -- exactly as the fused trainer does each step.
         ver = sum(p._version for p in ps)
-        if ver != self._ver:          # torch-side in-place updates (optimizer.step, load_state_dict)
+        if ver != self._ver or not self.weights_static:
             self._eng.params_changed()
             self._ver = ver
         return self._eng

@@ -85,20 +85,24 @@ def rec(thunk):
 
 # ------------------------------------------------------------------ optional per-kernel timing (bench.py)
 class KernelProfiler:
-    """HIP-event timing of individual entry points on the launch stream (torch's current stream), with the
+    """HIP-event timing of individual entry points on the launch stream (ops.cur_stream()), with the
     ALGORITHMIC bytes / flops of every launch (inputs + outputs read/written once, true K/N without padding)."""
 
     def __init__(self):
         self.rec = {}
 
-    def add(self, name, e0, e1, nbytes, flops):
-        self.rec.setdefault(name, []).append((e0, e1, nbytes, flops))
+    def add(self, name, e0, e1, nbytes, flops, stream):
+        self.rec.setdefault(name, []).append((e0, e1, nbytes, flops, stream))
 
     def summary(self):
+        """per region: launches, summed bracket time, algorithmic bytes / flops, and the bracket time per launch stream"""
         out = {}
         for name, rows in self.rec.items():
-            ms = sum(a.elapsed_time(b) for a, b, _, _ in rows)
-            out[name] = {"launches": len(rows), "ms": ms, "bytes": sum(r[2] for r in rows), "flops": sum(r[3] for r in rows)}
+            per_stream = {}
+            for a, b, _, _, st in rows:
+                per_stream[st] = per_stream.get(st, 0.0) + a.elapsed_time(b)
+            out[name] = {"launches": len(rows), "ms": sum(per_stream.values()), "bytes": sum(r[2] for r in rows),
+                         "flops": sum(r[3] for r in rows), "ms_by_stream": per_stream}
         return out
 
 
@@ -113,12 +117,13 @@ class _Timed:
 
     def __enter__(self):
         self.e0 = torch.cuda.Event(enable_timing=True)
-        self.e0.record()
+        self.e0.record(cur_stream())      # the stream THIS package launches on (side-stream sections redirect only that)
 
     def __exit__(self, *a):
         e1 = torch.cuda.Event(enable_timing=True)
-        e1.record()
-        PROFILER.add(self.name, self.e0, e1, self.nbytes, self.flops)
+        st = cur_stream()
+        e1.record(st)
+        PROFILER.add(self.name, self.e0, e1, self.nbytes, self.flops, st.cuda_stream)
 
 
 class _Untimed:

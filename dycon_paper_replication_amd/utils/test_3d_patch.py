@@ -61,7 +61,10 @@ def test_single_case(model, image, stride_xy, stride_z, patch_size, num_classes=
     p0, p1, p2 = patch_size
     stream = lambda: torch.cuda.current_stream().cuda_stream   # noqa: E731
     was_training = model.training
+    was_static = getattr(model, "weights_static", None)
     model.eval()
+    if was_static is not None:
+        model.weights_static = True      # no parameter changes between the windows: pack the weights once (networks/_base.py)
     try:
         with torch.no_grad():
             for i in range(0, len(wins), batch_size):
@@ -74,6 +77,8 @@ def test_single_case(model, image, stride_xy, stride_z, patch_size, num_classes=
                           cnt.data_ptr(), ww, hh, dd, stream())
     finally:
         model.train(was_training)
+        if was_static is not None:
+            model.weights_static = was_static
     label = torch.empty((ww, hh, dd), dtype=torch.uint8, device=dev)
     prob = torch.empty_like(score)
     _lib.call("dycon_sw_finalize", score.data_ptr(), cnt.data_ptr(), score.numel(), 0.5, label.data_ptr(), prob.data_ptr(), stream())

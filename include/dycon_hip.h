@@ -216,6 +216,40 @@ int dycon_step_loss(const float* vals, const float* fecl, float l_weight, float 
                     float u_weight, int dice_kind, int cons_kind, float* out, int* nonfinite,
                     dycon_stream_t stream);
 
+/* ---------------------------------------------------------------- the reference's loss callables, reference semantics
+ * The fused pass above takes LOGITS; the reference's own step body instead calls utils/losses.py on PROBABILITIES it computed
+ * with torch (train_DyCON_BraTS19.py:308-314,352).  These entry points implement those callables literally, so that loop body
+ * runs unchanged on this library.  All tensors are fp32 and described by a strided (n, C, V) view (element strides): channel
+ * stride 1 for channels-last maps, V for plain NCDHW, element stride 2 for `probs[:, 1]`.  1 <= C <= 8. */
+typedef struct {
+    const void* p;          /* device pointer of element (0, 0, 0) */
+    long long sn, sc, sv;   /* element strides of the sample, channel and (flattened) voxel index */
+} dycon_view_t;
+/* losses.softmax_mse_loss(a, b, sigmoid) (utils/losses.py:65-82): out = (softmax(a,1) - softmax(b,1))^2, element-wise */
+int dycon_softmax_mse_fwd(const dycon_view_t* a, const dycon_view_t* b, const dycon_view_t* out, long long n, int C,
+                          long long V, int sigmoid, dycon_stream_t stream);
+/* ga = d sum(g * out) / d a  (the loss is symmetric: pass (b, a) for the gradient of the second argument) */
+int dycon_softmax_mse_bwd(const dycon_view_t* a, const dycon_view_t* b, const dycon_view_t* g, const dycon_view_t* ga,
+                          long long n, int C, long long V, int sigmoid, dycon_stream_t stream);
+/* losses.softmax_kl_loss(a, b, sigmoid) (utils/losses.py:85-104) = F.kl_div(log_softmax(a,1), softmax(b,1), 'mean'):
+ * out[0] = sum q (log q - log p) / (n C V); sum: one double of scratch (zeroed by the call). */
+int dycon_softmax_kl_fwd(const dycon_view_t* a, const dycon_view_t* b, long long n, int C, long long V, int sigmoid,
+                         double* sum, float* out, dycon_stream_t stream);
+/* grad = g_up[0] * d out / d (which == 0 ? a : b) */
+int dycon_softmax_kl_bwd(const dycon_view_t* a, const dycon_view_t* b, long long n, int C, long long V, int sigmoid,
+                         int which, const float* g_up, const dycon_view_t* grad, dycon_stream_t stream);
+/* losses.dice_loss(score, target) (utils/losses.py:8-16; C = 1, onehot = 0, target of the score's shape) and
+ * losses.DiceLoss(C)(inputs, target, weight, softmax) (utils/losses.py:156-192; onehot = 1: target is the (n, V) label map,
+ * class c's target is label == c):  out[0] = sum_c w_c (1 - (2 I_c + 1e-5)/(Z_c + Y_c + 1e-5)) / n_div, with the sums taken
+ * over the WHOLE view (batch-global, as the reference).  target_kind: 0 float32, 1 one byte (uint8 / bool), 2 int64.
+ * weights_host: C host floats or NULL (= 1).  sums: 24 doubles of scratch, kept for the backward. */
+int dycon_dice_fwd(const dycon_view_t* score, const dycon_view_t* target, int target_kind, int onehot, long long n, int C,
+                   long long V, int softmax, const float* weights_host, float n_div, double* sums, float* out,
+                   dycon_stream_t stream);
+int dycon_dice_bwd(const dycon_view_t* score, const dycon_view_t* target, int target_kind, int onehot, long long n, int C,
+                   long long V, int softmax, const float* weights_host, float n_div, const double* sums, const float* g_up,
+                   const dycon_view_t* grad, dycon_stream_t stream);
+
 /* rows of (R, C): y = x / max(||x||, eps)   (F.normalize, train_DyCON_BraTS19.py:316-323) */
 int dycon_l2norm_fwd(const void* x, void* y, float* norms, int dtype, long long R, int C, float eps,
                      dycon_stream_t stream);

@@ -353,18 +353,20 @@ def _sub(t):
     return t[..., ::2, ::2, ::2]
 
 
-def gen_full_nets():
+def _full_nets(dtype):
+    """forward + objective gradients of the reference nets in `dtype` (fp32: the fixture; fp64: its twin for tolerance budgeting)"""
     rng = np.random.default_rng(606)
-    x = rng_t(rng, 2, 1, 32, 32, 32)
+    c = lambda t: t.to(dtype)  # noqa: E731
+    x = c(rng_t(rng, 2, 1, 32, 32, 32))
     out = {"x_seed": np.array(606)}
     # ---- V-Net: the reference class itself (no head) + composite head
-    p = onets.make_vnet_params(seed=11)
-    net = VNetWithHead(2)
+    p = {k: (c(v) if v.is_floating_point() else v) for k, v in onets.make_vnet_params(seed=11).items()}
+    net = VNetWithHead(2).to(dtype)
     net.load_flat(p)
     net.train()
     _, logits, feats = net(x)
-    r1 = rng_t(rng, *logits.shape)
-    r2 = rng_t(rng, *feats.shape)
+    r1 = c(rng_t(rng, *logits.shape))
+    r2 = c(rng_t(rng, *feats.shape))
     names = [k for k, _ in net.flat_named_parameters()]
     grads = torch.autograd.grad((logits * r1).sum() + (feats * r2).sum(), [v for _, v in net.flat_named_parameters()])
     out.update({"vnet.logits_sub": _sub(logits), "vnet.logits_stats": stats(logits), "vnet.feats": feats,
@@ -376,15 +378,15 @@ def gen_full_nets():
     plain = net.vnet(x)
     assert torch.equal(plain, logits)
     # ---- U-Net through the reference factory
-    pu = onets.make_unet_params(seed=12)
-    unet = ref_factory.net_factory_3d("unet_3D", 1, 2, 2)
+    pu = {k: (c(v) if v.is_floating_point() else v) for k, v in onets.make_unet_params(seed=12).items()}
+    unet = ref_factory.net_factory_3d("unet_3D", 1, 2, 2).to(dtype)
     unet.load_state_dict(pu)
     unet.train()
     unet.dropout1.p = 0.0
     unet.dropout2.p = 0.0
     sdf, ulog, ufeat = unet(x)
-    r3 = rng_t(rng, *ulog.shape)
-    r4 = rng_t(rng, *ufeat.shape)
+    r3 = c(rng_t(rng, *ulog.shape))
+    r4 = c(rng_t(rng, *ufeat.shape))
     unames = [k for k, _ in unet.named_parameters()]
     # the sdf head (tanh(final(up1))) is discarded by the training step, so it is left out of the objective:
     # final.* get no gradient (None -> zero statistics), exactly as in train_DyCON_BraTS19.py:304
@@ -393,28 +395,42 @@ def gen_full_nets():
                 "unet.feats": ufeat, "unet.param_seed": np.array(12)})
     out["unet.grad_stats"] = np.stack([stats(g) for g in ugr])
     out["unet.grad_names"] = np.array(unames)
+    return out
+
+
+F64_KEYS_FULL = ("logits_sub", "logits_stats", "feats", "grad_stats")
+
+
+def gen_full_nets():
+    out = _full_nets(torch.float32)
+    twin = _full_nets(torch.float64)      # same inputs / weights (fp32 values), reference modules run in double
+    for net in ("vnet", "unet"):
+        for k in F64_KEYS_FULL:
+            out[f"{net}.{k}.f64"] = twin[f"{net}.{k}"]
     save("full_nets", **out)
 
 
 # ----------------------------------------------------------------------------- full step traces
-def _ref_step_trace(kind, n_steps=2):
-    """Drive the imported reference modules/losses in the exact order of train_DyCON_BraTS19.py:298-372."""
+def _ref_step_trace(kind, n_steps=2, dtype=torch.float32):
+    """Drive the imported reference modules/losses in the exact order of train_DyCON_BraTS19.py:298-372.
+    dtype=float64: the same trace with every module, input and loss in double (tolerance-budget twin)."""
     rng = np.random.default_rng(707 if kind == "unet_3D" else 708)
     B, LB, S = 2, 1, 32
+    cast = lambda d: {k: (v.to(dtype) if v.is_floating_point() else v) for k, v in d.items()}  # noqa: E731
     if kind == "unet_3D":
-        model = ref_factory.net_factory_3d("unet_3D", 1, 2, 2)
-        ema = ref_factory.net_factory_3d("unet_3D", 1, 2, 2)
-        model.load_state_dict(onets.make_unet_params(seed=21))
-        ema.load_state_dict(onets.make_unet_params(seed=22))
+        model = ref_factory.net_factory_3d("unet_3D", 1, 2, 2).to(dtype)
+        ema = ref_factory.net_factory_3d("unet_3D", 1, 2, 2).to(dtype)
+        model.load_state_dict(cast(onets.make_unet_params(seed=21)))
+        ema.load_state_dict(cast(onets.make_unet_params(seed=22)))
         for m_ in (model, ema):
             m_.dropout1.p = 0.0
             m_.dropout2.p = 0.0
         s_named = lambda: list(model.named_parameters())   # noqa: E731
         t_named = lambda: list(ema.named_parameters())     # noqa: E731
     else:
-        model, ema = VNetWithHead(2), VNetWithHead(2)
-        model.load_flat(onets.make_vnet_params(seed=21))
-        ema.load_flat(onets.make_vnet_params(seed=22))
+        model, ema = VNetWithHead(2).to(dtype), VNetWithHead(2).to(dtype)
+        model.load_flat(cast(onets.make_vnet_params(seed=21)))
+        ema.load_flat(cast(onets.make_vnet_params(seed=22)))
         s_named = lambda: list(model.flat_named_parameters())   # noqa: E731
         t_named = lambda: list(ema.flat_named_parameters())     # noqa: E731
     for _, p_ in t_named():
@@ -428,9 +444,9 @@ def _ref_step_trace(kind, n_steps=2):
            "rng_seed": np.array(707 if kind == "unet_3D" else 708)}
     iter_num = 0
     for step in range(n_steps):
-        vol = rng_t(rng, B, 1, S, S, S)
+        vol = rng_t(rng, B, 1, S, S, S).to(dtype)
         lab = blob_labels(rng, B, S, S, S)
-        noise = torch.clamp(rng_t(rng, B, 1, S, S, S) * 0.1, -0.2, 0.2)
+        noise = torch.clamp(rng_t(rng, B, 1, S, S, S) * 0.1, -0.2, 0.2).to(dtype)
         epoch = step * 700          # exercise the threshold ramp
         beta = ref_dycon.adaptive_beta(epoch=epoch, total_epochs=3334, max_beta=5.0, min_beta=0.5)
         _, s_logits, s_feat = model(vol)
@@ -443,7 +459,7 @@ def _ref_step_trace(kind, n_steps=2):
         Bf, C = s_feat.shape[:2]
         s_emb = F.normalize(s_feat.view(Bf, C, -1).transpose(1, 2), dim=-1)
         t_emb = F.normalize(t_feat.view(Bf, C, -1).transpose(1, 2), dim=-1)
-        mask = (F.avg_pool3d(lab.float(), kernel_size=8, stride=8) > 0.5).float().reshape(Bf, -1).unsqueeze(1)
+        mask = (F.avg_pool3d(lab.float(), kernel_size=8, stride=8) > 0.5).to(dtype).reshape(Bf, -1).unsqueeze(1)
         f_loss = fecl(feat=s_emb, mask=mask, teacher_feat=t_emb, gambling_uncertainty=None, epoch=epoch)
         u_loss = uncl(s_logits, t_logits, beta)
         cons = ref_losses.softmax_mse_loss(s_prob[LB:], t_prob[LB:]).mean()
@@ -470,9 +486,17 @@ def _ref_step_trace(kind, n_steps=2):
     return out
 
 
+F64_KEYS_STEP = ("scalars", "logits_sub", "t_logits_sub", "feat_stats", "grad_stats", "student_stats", "teacher_stats")
+
+
 def gen_steps():
-    save("step_unet", **_ref_step_trace("unet_3D"))
-    save("step_vnet", **_ref_step_trace("vnet"))
+    for name, kind in (("step_unet", "unet_3D"), ("step_vnet", "vnet")):
+        out = _ref_step_trace(kind)
+        twin = _ref_step_trace(kind, dtype=torch.float64)
+        for step in range(2):
+            for k in F64_KEYS_STEP:
+                out[f"s{step}.{k}.f64"] = twin[f"s{step}.{k}"]
+        save(name, **out)
 
 
 if __name__ == "__main__":

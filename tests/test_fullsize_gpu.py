@@ -1,0 +1,203 @@
+"""GPU parity at the REAL sizes of BASELINE.json configs 2 and 3 (bf16 storage, B = 4 (2+2), 96^3 and 112x112x96).
+
+Op level: the layer shapes the benchmark step actually launches -- the persistent 96^3 kernels walking ~27 tiles per workgroup
+with the 2-deep halo prefetch, the LDS-halo kernel with its per-XCD tile remap, the bf16 weight-gradient kernel with its
+contiguous split ranges -- against F.conv3d / F.group_norm (fp32, CPU) on the same bf16-rounded inputs.  Outputs are checked
+ELEMENT-WISE (a wrong 4x8x8 tile is ~1e-4 of the voxels and invisible in a max-norm-relative bound taken over the whole tensor
+only if the bound is loose; here every element must be within bf16 rounding of the fp32 value).
+
+Step level: one full DyCON step at 96^3 / 112x112x96, B = 4 (2+2), against oracle/step.py: fp32 storage to the north-star's
+1e-4 on every loss scalar, bf16 storage on the scalars and on the direction of the flat gradient measured against the ORACLE's
+gradient, with PyTorch's own bf16 autocast of the oracle step as the noise budget (train_DyCON_BraTS19.py:147,
+train_DyCON_Pancreas.py:99).
+"""
+import zlib
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+if torch.cuda.is_available():
+    from dycon_paper_replication_amd import ops
+    from dycon_paper_replication_amd.engine import DropoutSpec
+    from dycon_paper_replication_amd.trainer import DyconTrainer, TrainConfig
+from oracle import nets as ON
+from oracle import step as OS
+from test_ops_gpu import mini_engine, nc, nd
+
+DEV = "cuda:0"
+T = torch.from_numpy
+BF = torch.bfloat16
+
+
+def assert_bf16_elementwise(got, ref, what, acc_noise=1e-3):
+    """every element of a bf16-stored result within bf16 rounding (2^-8 relative, doubled) of the fp32 reference, plus fp32
+    accumulation-order noise `acc_noise` x rms(ref).  Reports the worst 4x8x8 voxel tile on failure."""
+    got, ref = got.float(), ref.float()
+    rms = float(ref.pow(2).mean().sqrt())
+    excess = (got - ref).abs() - (2.0 ** -7) * ref.abs() - acc_noise * rms
+    worst = float(excess.max())
+    if worst > 0:
+        idx = np.unravel_index(int(excess.argmax()), excess.shape)
+        bad = int((excess > 0).sum())
+        tile = (idx[0], idx[2] // 4, idx[3] // 8, idx[4] // 8)
+        raise AssertionError(f"{what}: {bad} elements off (worst excess {worst:.3e}, rms {rms:.3e}) first at {idx}, "
+                             f"sample/tile(4x8x8) {tile}")
+
+
+# kind, cin, cout, spatial -- the layers of the V-Net / U-Net step at 96^3 and 112x112x96, B = 4
+FULL_CASES = [
+    ("k3", 1, 16, (96, 96, 96)),      # conv_k3_c1 (persistent, first layer)
+    ("k3", 16, 16, (96, 96, 96)),     # conv_k3_p16 (persistent, weight-stationary)
+    ("k3", 16, 16, (112, 112, 96)),   # Pancreas geometry: partial tiles in H (112 = 14 x 8) ...
+    ("k3", 32, 32, (48, 48, 48)),     # conv_k3_lds <32,2,4>
+    ("k3", 64, 64, (24, 24, 24)),     # conv_k3_lds <32,4,2>
+    ("k3", 32, 32, (56, 56, 48)),     # Pancreas level 2
+    ("k3", 64, 64, (28, 28, 24)),     # Pancreas level 3 (28 = 3.5 x 8: ragged tiles)
+    ("k3", 48, 16, (96, 96, 96)),     # U-Net decoder conv1 (chunk-major 48-channel input)
+    ("k3", 16, 32, (48, 48, 48)),     # U-Net conv2.conv1
+    ("k3", 128, 128, (12, 12, 12)),   # conv_k3_tile (split-K)
+    ("k3", 256, 256, (6, 6, 6)),
+    ("k2s2", 16, 32, (96, 96, 96)),
+    ("k2s2", 32, 64, (48, 48, 48)),
+    ("deconv", 32, 16, (48, 48, 48)),
+    ("deconv", 64, 32, (24, 24, 24)),
+]
+
+
+@pytest.mark.parametrize("kind,cin,cout,sp", FULL_CASES)
+def test_conv_full_size_bf16(kind, cin, cout, sp):
+    rng = np.random.default_rng(zlib.crc32(repr((kind, cin, cout, sp)).encode()))
+    B = 4
+    k = {"k3": 3, "k2s2": 2, "deconv": 2}[kind]
+    wshape = (cin, cout, k, k, k) if kind == "deconv" else (cout, cin, k, k, k)
+    w = T((rng.standard_normal(wshape) / np.sqrt(cin * k ** 3)).astype(np.float32))
+    b = T(rng.standard_normal(cout).astype(np.float32))
+    x = torch.randn((B, cin) + sp, generator=torch.Generator().manual_seed(int(rng.integers(1 << 30)))).bfloat16().float()
+    xr = x.clone().requires_grad_(cin > 1)
+    # the kernels multiply bf16-rounded weights; the rounded copy is the autograd LEAF (a gradient flowing back through a
+    # .bfloat16() cast would itself be rounded to bf16)
+    wr = w.bfloat16().float().requires_grad_(True)
+    br = b.clone().requires_grad_(True)
+    wq = wr
+    if kind == "k3":
+        yr = F.conv3d(xr, wq, br, padding=1)
+    elif kind == "k2s2":
+        yr = F.conv3d(xr, wq, br, stride=2)
+    else:
+        yr = F.conv_transpose3d(xr, wq, br, stride=2)
+    gy = torch.randn(tuple(yr.shape), generator=torch.Generator().manual_seed(7)).bfloat16().float()
+    yr.backward(gy)
+
+    e = mini_engine({"l.weight": w, "l.bias": b}, BF)
+    xd = nd(x, BF)
+    y = e._conv("l", xd, kind, need_gx=cin > 1)
+    e.G[id(y)] = nd(gy, BF)
+    for fn in reversed(e.tape):
+        fn()
+    torch.cuda.synchronize()
+    assert_bf16_elementwise(nc(y), yr.detach(), f"y {kind} {cin}->{cout} @ {sp}")
+    if cin > 1:
+        assert_bf16_elementwise(nc(e.G[id(xd)]), xr.grad, f"gx {kind} {cin}->{cout} @ {sp}")
+    # weight / bias gradients: fp32 sums over up to 3.5 M voxels of exact bf16 x bf16 products; only the summation order differs
+    # from the CPU's.  One dropped 4x4x8 tile would move an element by ~1/sqrt(#tiles) ~ 1e-2 of the scale.
+    for name, got, ref in (("gw", e.g["l.weight"], wr.grad), ("gb", e.g["l.bias"], br.grad)):
+        err = float((got.cpu() - ref).abs().max())
+        scale = float(ref.abs().max())
+        assert err <= 1e-3 * scale, f"{name} {kind} {cin}->{cout} @ {sp}: max err {err:.3e} vs scale {scale:.3e}"
+
+
+@pytest.mark.parametrize("C,G,sp,mode", [(16, 16, (96, 96, 96), "relu"), (16, 16, (96, 96, 96), "skip"), (32, 16, (48, 48, 48), "relu"),
+                                         (16, 16, (112, 112, 96), "relu"), (64, 16, (24, 24, 24), "skip")])
+def test_groupnorm_full_size_bf16(C, G, sp, mode):
+    """GroupNorm(16) + ReLU (+ skip add) forward / backward at the step's real shapes, bf16 storage, B = 4."""
+    gen = torch.Generator().manual_seed(C + sp[0])
+    B = 4
+    z = (torch.randn((B, C) + sp, generator=gen) * 1.5 + 0.3).bfloat16().float()
+    gamma = 1 + 0.2 * torch.randn(C, generator=gen)
+    beta = 0.2 * torch.randn(C, generator=gen)
+    skip = torch.randn((B, C) + sp, generator=gen).bfloat16().float() if mode == "skip" else None
+    zr = z.clone().requires_grad_(True)
+    gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    yr = F.relu(F.group_norm(zr, G, gr, br, 1e-5))
+    if skip is not None:
+        yr = yr + skip
+    gy = torch.randn(tuple(yr.shape), generator=gen).bfloat16().float()
+    yr.backward(gy)
+    e = mini_engine({"n.weight": gamma, "n.bias": beta}, BF)
+    zd = nd(z, BF)
+    sd = nd(skip, BF) if skip is not None else None
+    y = e._norm("n", zd, "gn", relu=True, skip=sd)
+    ycopy = y.clone()
+    e.G[id(y)] = nd(gy, BF)
+    for fn in reversed(e.tape):
+        fn()
+    torch.cuda.synchronize()
+    assert_bf16_elementwise(nc(ycopy), yr.detach(), f"gn y C={C} @ {sp}")
+    assert_bf16_elementwise(nc(e.G[id(zd)]), zr.grad, f"gn gz C={C} @ {sp}", acc_noise=2e-3)
+    for name, got, ref in (("dgamma", e.g["n.weight"], gr.grad), ("dbeta", e.g["n.bias"], br.grad)):
+        err = float((got.cpu() - ref).abs().max())
+        assert err <= 1e-3 * float(ref.abs().max()) + 1e-3, f"{name}: {err}"
+
+
+def _oracle_step(patch, B, LB, seed):
+    from dycon_paper_replication_amd.synthetic import make_batch
+    vol, lab, noise = make_batch(seed, B, patch)
+    st = OS.StepState(student=ON.make_vnet_params(41), teacher=ON.make_vnet_params(42))
+    ref = OS.train_step(OS.StepConfig(net_type="vnet", labeled_bs=LB), st, vol, lab, noise, 5.0, 0)
+    return vol, lab, noise, st, ref
+
+
+KEYS = ("loss", "ce", "dice", "cons", "fecl", "uncl")
+
+
+@pytest.mark.parametrize("patch", [(96, 96, 96), (112, 112, 96)])
+def test_step_full_size_vs_oracle(patch):
+    """BASELINE config 2 (96^3) and config 3 (the reference's Pancreas patch 112x112x96): one V-Net step, B = 4 (2+2), against the
+    CPU oracle step.  fp32 storage: every loss scalar and the gradient norm at the north-star's 1e-4 (5e-4 for the norm: see
+    test_trainer_gpu).  bf16 storage: scalars within 3e-2 and the flat gradient's direction against the ORACLE's gradient."""
+    B, LB = 4, 2
+    vol, lab, noise, st, ref = _oracle_step(patch, B, LB, 77)
+    exp = np.array([float(ref[k]) for k in KEYS])
+    names = list(ref["grads"])
+    gref = torch.cat([ref["grads"][k].reshape(-1) for k in names]).double()
+    with torch.autocast("cpu", dtype=torch.bfloat16):
+        st_ac = OS.StepState(student=ON.make_vnet_params(41), teacher=ON.make_vnet_params(42))
+        ref_ac = OS.train_step(OS.StepConfig(net_type="vnet", labeled_bs=LB), st_ac, vol, lab, noise, 5.0, 0)
+    gac = torch.cat([ref_ac["grads"][k].float().reshape(-1) for k in names]).double()
+    cos_autocast = float((gac * gref).sum() / (gac.norm() * gref.norm()))
+    print(f"torch.autocast(bf16) oracle step vs fp32 oracle step: grad cos {cos_autocast:.6f}")
+    off = DropoutSpec("off")
+    for dt in (torch.float32, BF):
+        tr = DyconTrainer(TrainConfig(model="vnet", labeled_bs=LB, batch_size=B, dtype=dt), DEV,
+                          student_init=ON.make_vnet_params(41), teacher_init=ON.make_vnet_params(42))
+        out = tr.step(vol.to(DEV), lab.to(DEV), noise=noise.to(DEV), s_drop=off, t_drop=off, epoch=0, beta=5.0)
+        got = np.array([float(out[k]) for k in KEYS])
+        ggot = torch.cat([tr.g[k].reshape(-1) for k in names]).double().cpu()
+        cos = float((ggot * gref).sum() / (ggot.norm() * gref.norm()))
+        ratio = float(ggot.norm() / gref.norm())
+        print(f"step {patch} {dt}: scalars rel err {np.abs(got - exp) / (np.abs(exp) + 1e-12)}, grad cos {cos:.6f}, norm ratio {ratio:.5f}")
+        if dt == BF:      # where the direction error sits (share of |g_hip - g_ref|^2 per parameter)
+            tot = float((ggot - gref).pow(2).sum())
+            rows = sorted(((float((tr.g[k].double().cpu() - ref["grads"][k].double()).pow(2).sum()) / tot, k,
+                            float(ref["grads"][k].norm()), float(tr.g[k].norm())) for k in names), reverse=True)[:12]
+            for share, k, nr, ng in rows:
+                print(f"    {share:6.3f} of the error in {k}: |ref| {nr:.3e} |hip| {ng:.3e}")
+        if dt == torch.float32:
+            np.testing.assert_allclose(got, exp, rtol=1e-4, atol=1e-6)
+            assert float(out["grad_sumsq"].sqrt()) == pytest.approx(float(ref["grad_norm"]), rel=5e-4)
+            assert cos > 0.99999
+            for k in ("block_one.conv.0.weight", "block_nine.conv.0.weight", "block_five.conv.3.weight", "out_conv.weight"):
+                np.testing.assert_allclose(tr.p[k].cpu().numpy(), st.student[k].numpy(), rtol=1e-4, atol=1e-6, err_msg=k)
+        else:
+            np.testing.assert_allclose(got, exp, rtol=3e-2, atol=3e-3)
+            # budget for the direction error: what PyTorch's OWN bf16 mixed precision (torch.autocast on the oracle step, same
+            # inputs and weights) loses against fp32.  Measured at 96^3: autocast 0.99229, this path 0.99268 -- the bf16-storage
+            # step sits at the noise floor of bf16 training itself; a tile / range bug costs far more (and is caught element-wise
+            # by the op-level tests above).
+            assert 1.0 - cos <= 1.5 * (1.0 - cos_autocast) + 1e-4 and cos >= 0.99 and 0.97 < ratio < 1.03, (cos, cos_autocast, ratio)
+        del tr
+        torch.cuda.empty_cache()
