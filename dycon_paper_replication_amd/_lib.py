@@ -46,6 +46,8 @@ SIGNATURES = {
     "dycon_trilinear_fwd": (I, [P, P, I, I, I, I, I, I, I, I, I, I, I, I, P]),
     "dycon_trilinear_bwd": (I, [P, P, I, I, I, I, I, I, I, I, I, I, I, I, P]),
     "dycon_copy_channels": (I, [P, I, I, P, I, I, L, I, I, P]),
+    "dycon_relu_fwd": (I, [P, P, P, P, I, I, L, I, P]),
+    "dycon_relu_bwd": (I, [P, P, P, P, I, I, L, I, P]),
     "dycon_scale_channels": (I, [P, P, P, I, I, L, I, P]),
     "dycon_mul_mask": (I, [P, P, F, P, I, L, P]),
     "dycon_dropout_philox": (I, [P, P, I, L, F, U64, U64, P]),

@@ -249,6 +249,27 @@ __global__ void scale_channels_kernel(const T* __restrict__ X, const float* __re
     }
 }
 
+// normalization='none' blocks of the V-Net (VNet.py:23-24, 87, 114): y = relu(z) * chan_scale[b, c] + skip
+template <typename T>
+__global__ void relu_fwd_kernel(const T* __restrict__ Z, const T* __restrict__ skip, const float* __restrict__ cs, T* __restrict__ Y,
+                                long long V, int C, long long total) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        float v = fmaxf(ldf(Z + i), 0.f);
+        if (cs) v *= cs[(i / (V * C)) * C + (int)(i % C)];
+        if (skip) v += ldf(skip + i);
+        stf(Y + i, v);
+    }
+}
+template <typename T>
+__global__ void relu_bwd_kernel(const T* __restrict__ Z, const T* __restrict__ GY, const float* __restrict__ cs, T* __restrict__ GZ,
+                                long long V, int C, long long total) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        float g = ldf(Z + i) > 0.f ? ldf(GY + i) : 0.f;
+        if (cs) g *= cs[(i / (V * C)) * C + (int)(i % C)];
+        stf(GZ + i, g);
+    }
+}
+
 template <typename T>
 __global__ void mul_mask_kernel(const T* __restrict__ X, const float* __restrict__ mask, float inv_keep, T* __restrict__ Y,
                                 long long n) {
@@ -387,6 +408,24 @@ extern "C" int dycon_copy_channels(const void* src, int lds, int soff, void* dst
                                    int dtype, dycon_stream_t stream) {
     DYCON_REQUIRE(src && dst && rows > 0 && C > 0 && soff >= 0 && doff >= 0 && soff + C <= lds && doff + C <= ldd, "copy_channels: bad arguments");
     DYCON_DISPATCH(dtype, { copy_channels_kernel<T><<<sgrid(rows * C), 256, 0, stream>>>((const T*)src, lds, soff, (T*)dst, ldd, doff, rows, C); });
+    DYCON_LAUNCH_CHECK();
+    return DYCON_OK;
+}
+
+extern "C" int dycon_relu_fwd(const void* z, const void* skip, const float* chan_scale, void* y, int dtype, int B, long long V, int C,
+                              dycon_stream_t stream) {
+    DYCON_REQUIRE(z && y && B > 0 && V > 0 && C > 0, "relu_fwd: bad arguments");
+    const long long total = (long long)B * V * C;
+    DYCON_DISPATCH(dtype, { relu_fwd_kernel<T><<<sgrid(total), 256, 0, stream>>>((const T*)z, (const T*)skip, chan_scale, (T*)y, V, C, total); });
+    DYCON_LAUNCH_CHECK();
+    return DYCON_OK;
+}
+
+extern "C" int dycon_relu_bwd(const void* z, const void* gy, const float* chan_scale, void* gz, int dtype, int B, long long V, int C,
+                              dycon_stream_t stream) {
+    DYCON_REQUIRE(z && gy && gz && B > 0 && V > 0 && C > 0, "relu_bwd: bad arguments");
+    const long long total = (long long)B * V * C;
+    DYCON_DISPATCH(dtype, { relu_bwd_kernel<T><<<sgrid(total), 256, 0, stream>>>((const T*)z, (const T*)gy, chan_scale, (T*)gz, V, C, total); });
     DYCON_LAUNCH_CHECK();
     return DYCON_OK;
 }

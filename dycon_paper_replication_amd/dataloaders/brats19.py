@@ -57,6 +57,19 @@ def _pad_to(sample_arrays, output_size):
     return sample_arrays
 
 
+class SagittalToAxial(object):
+    """First transform of the reference's BraTS training pipeline (train_DyCON_BraTS19.py:238-242, dataloaders/brats19.py:86-128):
+    image and label (H, W, D) -> (D, W, H).  numpy arrays or (device) tensors."""
+
+    def __call__(self, sample):
+        image, label = sample["image"], sample["label"]
+        if tuple(image.shape) != tuple(label.shape):
+            raise ValueError("Shape mismatch between image and label")
+        if torch.is_tensor(image):
+            return {"image": image.permute(2, 1, 0), "label": label.permute(2, 1, 0)}
+        return {"image": np.transpose(image, (2, 1, 0)), "label": np.transpose(label, (2, 1, 0))}
+
+
 class CenterCrop(object):
     def __init__(self, output_size):
         self.output_size = output_size

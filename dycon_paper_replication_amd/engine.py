@@ -20,6 +20,7 @@ from . import ops
 from ._lib import CONV_1X1, CONV_K2S2, CONV_K3
 
 UNET_FILTERS = (16, 32, 64, 128, 256)
+VNET_NORMS = ("groupnorm", "instancenorm", "batchnorm", "none")      # VNet.py:17-24
 
 
 # --------------------------------------------------------------------------------------
@@ -44,9 +45,11 @@ def projection_buffers():
 
 def vnet_param_spec(in_ch=1, n_classes=2, normalization="groupnorm", nf=16):
     """VNet.__init__ registration order (VNet.py:150-175) + the DyCON projection head."""
+    if normalization not in VNET_NORMS:
+        raise ValueError(f"normalization must be one of {VNET_NORMS}")
     spec = OrderedDict()
-    affine = normalization == "groupnorm"
-    step = 3
+    affine = normalization in ("groupnorm", "batchnorm")     # InstanceNorm3d: affine=False (VNet.py:21-22)
+    step = 2 if normalization == "none" else 3              # nn.Sequential indices: conv, [norm,] relu (VNet.py:16-24)
 
     def block(name, n, cin, cout):
         for i in range(n):
@@ -84,6 +87,32 @@ def vnet_param_spec(in_ch=1, n_classes=2, normalization="groupnorm", nf=16):
     spec["out_conv.bias"] = (n_classes,)
     _projection_spec(spec, 16 * nf)
     return spec
+
+
+def vnet_norm_sites(normalization="groupnorm"):
+    """state_dict prefixes of the V-Net's norm modules, in registration order (VNet.py:150-174)."""
+    if normalization == "none":
+        return []
+    sites = []
+    for blk, n, nxt in (("block_one", 1, "block_one_dw"), ("block_two", 2, "block_two_dw"), ("block_three", 3, "block_three_dw"),
+                        ("block_four", 3, "block_four_dw"), ("block_five", 3, "block_five_up"), ("block_six", 3, "block_six_up"),
+                        ("block_seven", 3, "block_seven_up"), ("block_eight", 2, "block_eight_up"), ("block_nine", 1, None)):
+        sites += [f"{blk}.conv.{3 * i + 1}" for i in range(n)]
+        if nxt:
+            sites.append(f"{nxt}.conv.1")
+    return sites
+
+
+def net_buffers(net_type, normalization="groupnorm", params=None):
+    """BatchNorm buffers of the net in state_dict order: the V-Net's own (normalization='batchnorm', VNet.py:17-18) + the head's."""
+    bufs = OrderedDict()
+    if net_type == "vnet" and normalization == "batchnorm":
+        spec = params if params is not None else vnet_param_spec(normalization=normalization)
+        for site in vnet_norm_sites(normalization):
+            c = tuple(spec[site + ".weight"])
+            bufs[site + ".running_mean"], bufs[site + ".running_var"], bufs[site + ".num_batches_tracked"] = c, c, ()
+    bufs.update(projection_buffers())
+    return bufs
 
 
 def unet_param_spec(in_ch=1, n_classes=2):
@@ -135,8 +164,8 @@ class Engine:
     def __init__(self, net_type: str, params: Dict[str, torch.Tensor], grads: Optional[Dict[str, torch.Tensor]] = None,
                  buffers: Optional[Dict[str, torch.Tensor]] = None, dtype=torch.float32, scale_factor=2,
                  normalization="groupnorm"):
-        if net_type == "vnet" and normalization not in ("groupnorm", "instancenorm"):
-            raise NotImplementedError("the HIP V-Net supports normalization='groupnorm' (north-star) or 'instancenorm'")
+        if net_type == "vnet" and normalization not in VNET_NORMS:
+            raise ValueError(f"normalization must be one of {VNET_NORMS} (VNet.py:17-24)")
         self.net_type, self.p, self.g, self.buf = net_type, params, grads, buffers or {}
         self.dtype, self.scale_factor, self.normalization = dtype, scale_factor, normalization
         self.gen = 0                 # bump whenever parameter values change (invalidates packed weights)
@@ -360,6 +389,17 @@ class Engine:
             Nb, G, V = 1, C, B * V
             gamma, beta = self.p[prefix + ".weight"], self.p[prefix + ".bias"]
             rm, rv = self.buf.get(prefix + ".running_mean"), self.buf.get(prefix + ".running_var")
+        elif kind == "none":           # normalization='none': conv -> ReLU (VNet.py:23-24); same fusions (dropout factor, skip add)
+            assert relu
+            y = ops.relu_fwd(z, skip, chan_scale)
+            if self.recording:
+                def bwd_relu():
+                    gy = self._take(y)
+                    if skip is not None:
+                        self._give(skip, gy)
+                    self._give(z, ops.relu_bwd(z, gy, chan_scale))
+                self.tape.append(bwd_relu)
+            return y
         else:
             raise ValueError(kind)
         # z is kept: the ReLU is not invertible, so the backward needs the pre-norm tensor (xhat of the
@@ -462,25 +502,27 @@ class Engine:
 
     # ---------------------------------------------------------------- V-Net
     def _vnet(self, x, training):
-        nk = "gn" if self.normalization == "groupnorm" else "in"
+        nk = {"groupnorm": "gn", "instancenorm": "in", "batchnorm": "bn", "none": "none"}[self.normalization]
+        st = 2 if nk == "none" else 3       # nn.Sequential index step: conv, [norm,] relu
 
-        def ngroups(t, conv):       # groups of the norm that follows this conv: GroupNorm(16, C) or InstanceNorm (G = C)
-            return 16 if nk == "gn" else self.p[conv + ".weight"].shape[0]
+        def ngroups(t, conv):       # groups of the one-launch norm that may take over this conv's split-K finish (GN / IN only)
+            return 16 if nk == "gn" else (self.p[conv + ".weight"].shape[0] if nk == "in" else 0)
 
         def block(name, t, n, first=False, drop=None):
             for i in range(n):
-                t = self._conv(f"{name}.conv.{3 * i}", t, "k3", need_gx=not (first and i == 0), norm_groups=ngroups(t, f"{name}.conv.{3 * i}"))
+                t = self._conv(f"{name}.conv.{st * i}", t, "k3", need_gx=not (first and i == 0), norm_groups=ngroups(t, f"{name}.conv.{st * i}"))
                 cs = None
                 if drop is not None and i == n - 1:
                     cs = self._channel_scale(t.shape[0], t.shape[-1], drop[0], 0.5, drop[1], t.device)
-                t = self._norm(f"{name}.conv.{3 * i + 1}", t, nk, chan_scale=cs)
+                t = self._norm(f"{name}.conv.{st * i + 1}", t, nk, chan_scale=cs, training=training)
             return t
 
         def down(name, t):
-            return self._norm(f"{name}.conv.1", self._conv(f"{name}.conv.0", t, "k2s2", norm_groups=ngroups(t, f"{name}.conv.0")), nk)
+            return self._norm(f"{name}.conv.1", self._conv(f"{name}.conv.0", t, "k2s2", norm_groups=ngroups(t, f"{name}.conv.0")), nk,
+                              training=training)
 
         def up(name, t, skip):
-            return self._norm(f"{name}.conv.1", self._conv(f"{name}.conv.0", t, "deconv"), nk, skip=skip)
+            return self._norm(f"{name}.conv.1", self._conv(f"{name}.conv.0", t, "deconv"), nk, skip=skip, training=training)
 
         x1 = block("block_one", x, 1, first=True)
         x2 = block("block_two", down("block_one_dw", x1), 2)

@@ -15,7 +15,7 @@ import torch
 import torch.nn as nn
 
 from .. import ops
-from ..engine import DropoutSpec, Engine, param_spec, projection_buffers
+from ..engine import DropoutSpec, Engine, net_buffers, param_spec
 
 
 def _register(root: nn.Module, dotted: str, tensor, buffer=False):
@@ -97,7 +97,7 @@ class HipSegNet(nn.Module):
         gen = torch.Generator().manual_seed(seed) if seed is not None else None
         for name, shape in spec.items():
             _register(self, name, self._init_tensor(name, shape, gen))
-        for name, shape in projection_buffers().items():
+        for name, shape in net_buffers(self.net_type, normalization, spec).items():
             if name.endswith("num_batches_tracked"):
                 t = torch.zeros((), dtype=torch.long)
             elif name.endswith("running_var"):

@@ -407,6 +407,22 @@ def scale_channels(x, scale):
     return y
 
 
+def relu_fwd(z, skip=None, chan_scale=None):
+    B, C = z.shape[0], z.shape[-1]
+    y = torch.empty_like(z)
+    with _Region("relu", z.numel() * _es(z) * (3 if skip is not None else 2), z.numel()):
+        call("dycon_relu_fwd", _p(z), _p(skip), _p(chan_scale), _p(y), dt(z), B, z.numel() // (B * C), C, _s())
+    return y
+
+
+def relu_bwd(z, gy, chan_scale=None):
+    B, C = z.shape[0], z.shape[-1]
+    gz = torch.empty_like(gy)
+    with _Region("relu", z.numel() * _es(z) * 3, z.numel()):
+        call("dycon_relu_bwd", _p(z), _p(gy), _p(chan_scale), _p(gz), dt(z), B, z.numel() // (B * C), C, _s())
+    return gz
+
+
 def mul_mask(x, mask, inv_keep):
     y = torch.empty_like(x)
     call("dycon_mul_mask", _p(x), _p(mask), inv_keep, _p(y), dt(x), x.numel(), _s())

@@ -70,7 +70,8 @@ class TrainConfig:
     overlap_wgrad: bool = True          # weight-gradient launches of the backward on a second HIP stream (off the dgrad chain)
     overlap_features: bool = True       # feature branch (projection head, embeddings, FeCL forward + backward) on its own stream
     replay: bool = True                 # after two eager steps of a given input signature, record the step's launch list once and
-                                        # re-issue it with patched scalars (the step is host-enqueue-bound: see DyconTrainer.step)
+                                        # re-issue it with patched scalars (the step is host-enqueue-bound: see DyconTrainer.step);
+                                        # single-process and data-parallel runs alike
 
 
 class DyconTrainer:
@@ -211,9 +212,10 @@ class DyconTrainer:
         The tensors in the returned dict are then the recorded step's buffers: valid until the next step."""
         c = self.cfg
         sig = None
-        # (single-process runs only: with a process group the step contains torch.distributed collectives, whose replay as
-        # recorded closures is not validated on RCCL -- the gloo rehearsal ran 8x slower -- so DDP ranks stay on the eager path)
-        if c.replay and self.world == 1 and noise is None and s_drop is None and t_drop is None and ops.PROFILER is None:
+        # With a process group the recorded list contains the step's torch.distributed calls as closures (the bucketed gradient
+        # all-reduces issued from the backward, the two accumulator exchanges, the join): re-issuing them is the same sequence of
+        # torch.distributed calls an eager step makes, on the same tensors (tests/test_ddp_gpu.py: replay == eager over 2 ranks).
+        if c.replay and noise is None and s_drop is None and t_drop is None and ops.PROFILER is None:
             sig = (tuple(volume.shape), volume.dtype, tuple(label.shape), label.dtype, torch.cuda.current_stream().cuda_stream)
         with ops.on_stream(None):
             if sig is None:
@@ -451,8 +453,9 @@ class DyconTrainer:
             st = torch.load(side, map_location="cpu", weights_only=True)
             st["student"] = student
             self.load_full_state(st)
-        else:                                                   # evaluation-style load: weights only, teacher = student (EMA restarts)
-            self.model.load_state_dict(student)
+        else:                                                   # evaluation-style load: student weights only.  The teacher keeps
+            self.model.load_state_dict(student)                 # its weights (as after create_model(ema=True), :229-230); with
+            #                                                     iter_num = 0 the first EMA update has alpha = 0: teacher := student
             for e in (self.s_eng, self.t_eng):
                 e.params_changed()
             self.model.params_changed()

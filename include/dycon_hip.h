@@ -168,6 +168,14 @@ int dycon_trilinear_bwd(const void* gy, void* gx, int dtype, int B, int Di, int 
 /* dst[row, doff + c] = src[row, soff + c]  (concat / split of channel slices) */
 int dycon_copy_channels(const void* src, int lds, int soff, void* dst, int ldd, int doff,
                         long long rows, int C, int dtype, dycon_stream_t stream);
+/* ReLU of the V-Net's normalization='none' blocks (VNet.py:23-24, 87, 114), with the Dropout3d channel factor and the decoder's
+ * skip add folded in like in the norm kernels: y = relu(z) * chan_scale[b, c] + skip; gz = (z > 0) * gy * chan_scale[b, c].
+ * skip / chan_scale may be NULL. */
+int dycon_relu_fwd(const void* z, const void* skip, const float* chan_scale, void* y, int dtype, int B, long long V, int C,
+                   dycon_stream_t stream);
+int dycon_relu_bwd(const void* z, const void* gy, const float* chan_scale, void* gz, int dtype, int B, long long V, int C,
+                   dycon_stream_t stream);
+
 /* y[b, v, c] = x[b, v, c] * scale[b, c]   (nn.Dropout3d(0.5), VNet.py:177,196,226; fwd and bwd) */
 int dycon_scale_channels(const void* x, const float* scale, void* y, int dtype, int B, long long V,
                          int C, dycon_stream_t stream);

@@ -86,23 +86,12 @@ def softmax_kl(in_logits, tgt_logits):
 
 
 # ------------------------------------------------------------------ FeCL
-def fecl(feat, mask, teacher_feat: Optional[torch.Tensor] = None,
-         gambling_uncertainty: Optional[torch.Tensor] = None, epoch=0, temperature=0.6, gamma=2.0,
-         use_focal=False, rampup_epochs=2000, lambda_cross=1.0):
-    """FeCLoss.forward, utils/dycon_losses.py:150-235, written per sample so that only one (N,N)
-    block set is alive at a time.
-
-    Kept exactly (SURVEY.md section 0 items 2-4): the *column* max stabiliser (detached), the
-    always-on positive focal weight (threshold >= 1.3 > any probability) which stays in the
-    autograd graph, the hard-negative focal weights that multiply zeros (omitted: value and
-    gradient are identical), the literal 1e-18 epsilons, the batch-global cross-branch ratio."""
+def _fecl_samples(feat, mask, teacher_feat, gambling_uncertainty, epoch, temperature, gamma, use_focal, rampup_epochs):
+    """per sample: (per-patch loss vector (N,), cross-branch numerator, cross-branch count) -- dycon_losses.py:172-231"""
     B, N, _ = feat.shape
     m = mask.reshape(B, N)
     eye = torch.eye(N, dtype=feat.dtype)
     off = 1 - eye
-    per_patch = []
-    cross_num = feat.new_zeros(())
-    cross_cnt = feat.new_zeros(())
     thr = threshold_rampup(epoch, rampup_epochs, 0.3, 0.5)
     for b in range(B):
         same = (m[b][:, None] == m[b][None, :]).to(feat.dtype)
@@ -115,21 +104,50 @@ def fecl(feat, mask, teacher_feat: Optional[torch.Tensor] = None,
         ell = -torch.log(P + 1e-18) * same * off
         denom = same.sum(-1) - 1 + 1e-18
         if gambling_uncertainty is not None:                       # :209-211 (overrides focal)
-            per_patch.append(ell.sum(-1) / denom * gambling_uncertainty[b])
+            per_patch = ell.sum(-1) / denom * gambling_uncertainty[b]
         elif use_focal:                                            # :196-206
             w = torch.where(same.bool(), (1 - P) ** gamma, torch.ones_like(P))
-            per_patch.append((ell * w).sum(-1) / denom)
+            per_patch = (ell * w).sum(-1) / denom
         else:
-            per_patch.append(ell.sum(-1) / denom)
+            per_patch = ell.sum(-1) / denom
+        num = cnt = feat.new_zeros(())
         if teacher_feat is not None:                               # :214-231
             S = feat[b] @ teacher_feat[b].t()
             hard = (diff.bool() & (S > thr)).to(feat.dtype)
-            cross_num = cross_num + (-torch.log(1 - S + 1e-18) * hard).sum()
-            cross_cnt = cross_cnt + hard.sum()
+            num, cnt = (-torch.log(1 - S + 1e-18) * hard).sum(), hard.sum()
+        yield per_patch, num, cnt
+
+
+def fecl(feat, mask, teacher_feat: Optional[torch.Tensor] = None,
+         gambling_uncertainty: Optional[torch.Tensor] = None, epoch=0, temperature=0.6, gamma=2.0,
+         use_focal=False, rampup_epochs=2000, lambda_cross=1.0):
+    """FeCLoss.forward, utils/dycon_losses.py:150-235, written per sample so that only one (N,N)
+    block set is alive at a time.
+
+    Kept exactly (SURVEY.md section 0 items 2-4): the *column* max stabiliser (detached), the
+    always-on positive focal weight (threshold >= 1.3 > any probability) which stays in the
+    autograd graph, the hard-negative focal weights that multiply zeros (omitted: value and
+    gradient are identical), the literal 1e-18 epsilons, the batch-global cross-branch ratio."""
+    per_patch = []
+    cross_num = feat.new_zeros(())
+    cross_cnt = feat.new_zeros(())
+    for pp, num, cnt in _fecl_samples(feat, mask, teacher_feat, gambling_uncertainty, epoch, temperature, gamma, use_focal, rampup_epochs):
+        per_patch.append(pp)
+        cross_num = cross_num + num
+        cross_cnt = cross_cnt + cnt
     loss = torch.stack(per_patch).mean()
     if teacher_feat is not None and cross_cnt.item() > 0:
         loss = loss + lambda_cross * cross_num / (cross_cnt + 1e-18)
     return loss
+
+
+def fecl_parts(feat, mask, teacher_feat=None, epoch=0, temperature=0.6, gamma=2.0, use_focal=False, rampup_epochs=2000):
+    """The accumulators a data-parallel rank contributes: (sum of per-patch losses, cross numerator, cross
+    count, rows = B*N).  fecl == student_sum / rows + cross_num / (cross_cnt + 1e-18) over the sums of all ranks."""
+    tot = num_t = cnt_t = feat.new_zeros(())
+    for pp, num, cnt in _fecl_samples(feat, mask, teacher_feat, None, epoch, temperature, gamma, use_focal, rampup_epochs):
+        tot, num_t, cnt_t = tot + pp.sum(), num_t + num, cnt_t + cnt
+    return tot, num_t, cnt_t, feat.shape[0] * feat.shape[1]
 
 
 def fecl_rowblocks(feat, mask, teacher_feat, epoch=0, temperature=0.6, gamma=2.0, use_focal=True, rampup_epochs=2000,

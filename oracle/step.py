@@ -141,3 +141,62 @@ def train_step(cfg: StepConfig, st: StepState, volume, label, noise, beta: float
     st.iter_num += 1
     out["skipped"] = False
     return out
+
+
+def ddp_train_step(cfg: StepConfig, states, shards, beta: float, epoch: int):
+    """The data-parallel iteration as the trainer runs it over W ranks, emulated in one process: every rank
+    forwards its own shard [labelled | unlabelled] (so the projection head's BatchNorm sees PER-RANK batch statistics, as in the
+    reference's DataParallel replicas), the Dice and FeCL-cross accumulators are summed over ranks (the 16 + 4-double
+    all-reduces), each rank differentiates its local objective with the two global-ratio terms pre-scaled by W, the gradients
+    are averaged (the arena all-reduce with 1/W folded into SGD), and every rank applies the same clip + SGD + EMA.
+    states: one StepState per rank (identical parameters, own BatchNorm buffers); shards: [(volume, label, noise)] per rank.
+    cfg.base_lr is the already scaled LR (x W, train_DyCON_BraTS19.py:108-110).  dice_variant 'fg', consistency 'mse'."""
+    assert cfg.dice_variant == "fg" and cfg.consistency_type == "mse"
+    W, LB = len(states), cfg.labeled_bs
+    names = list(nets.trainable(states[0].student).keys())
+    kw = dict(scale_factor=cfg.feature_scaler)
+    if cfg.net_type == "vnet":
+        kw["normalization"] = cfg.normalization
+    ranks = []
+    for st, (vol, lab, noise) in zip(states, shards):
+        sp = {k: (v.detach().clone().requires_grad_(True) if k in names else v) for k, v in st.student.items()}
+        _, s_logits, s_feat = nets.forward(cfg.net_type, vol, sp, update_buffers=True, **kw)
+        with torch.no_grad():
+            _, t_logits, t_feat = nets.forward(cfg.net_type, vol + noise, st.teacher, bn_training=cfg.teacher_bn_training,
+                                               update_buffers=cfg.teacher_bn_training, **kw)
+        s_prob, t_prob = F.softmax(s_logits, 1), F.softmax(t_logits, 1)
+        t1 = (lab[:LB] == 1).to(s_prob.dtype)
+        acc = dict(I=(s_prob[:LB, 1] * t1).sum(), Z=(s_prob[:LB, 1] ** 2).sum(), Y=(t1 * t1).sum())
+        k = lab.shape[1] // s_feat.shape[2]
+        stud, num, cnt, rows = L.fecl_parts(L.embed(s_feat), L.contrast_mask(lab, k), L.embed(t_feat) if cfg.use_teacher_loss else None,
+                                            epoch, cfg.temp, cfg.gamma, cfg.use_focal, cfg.rampup_epochs)
+        ranks.append(dict(sp=sp, acc=acc, stud=stud, num=num, cnt=cnt, rows=rows, ce=F.cross_entropy(s_logits[:LB], lab[:LB]),
+                          cons=L.softmax_mse(s_prob[LB:], t_prob[LB:]).mean(), uncl=L.uncl(s_logits, t_logits, beta)))
+    g = {k: sum(r["acc"][k].detach() for r in ranks) for k in ("I", "Z", "Y")}
+    numg, cntg = sum(r["num"].detach() for r in ranks), sum(r["cnt"].detach() for r in ranks)
+    rows_g = sum(r["rows"] for r in ranks)
+    cw = L.consistency_weight(states[0].iter_num, cfg.consistency, cfg.consistency_rampup)
+    avg = None
+    for r in ranks:
+        a = r["acc"]
+        dice_loc = 1 - (2 * (a["I"] + (g["I"] - a["I"].detach())) + 1e-5) / ((a["Z"] + (g["Z"] - a["Z"].detach())) + g["Y"] + 1e-5)
+        cross_loc = (r["num"] + (numg - r["num"].detach())) / (cntg + 1e-18) if (cfg.use_teacher_loss and float(cntg) > 0) else 0.0
+        local = cfg.l_weight * (r["ce"] + W * dice_loc) + cw * r["cons"] + cfg.u_weight * (W * r["stud"] / rows_g + W * cross_loc + r["uncl"])
+        gl = torch.autograd.grad(local, [r["sp"][k] for k in names], allow_unused=True)
+        gl = {k: v for k, v in zip(names, gl) if v is not None}
+        avg = gl if avg is None else {k: avg[k] + gl[k] for k in avg}
+    avg = {k: v / W for k, v in avg.items()}
+    dice = 1 - (2 * g["I"] + 1e-5) / (g["Z"] + g["Y"] + 1e-5)
+    fecl = sum(r["stud"].detach() for r in ranks) / rows_g + (numg / (cntg + 1e-18) if float(cntg) > 0 else 0.0)
+    ce, cons, uncl = (sum(r[k].detach() for r in ranks) / W for k in ("ce", "cons", "uncl"))
+    total = cfg.l_weight * (ce + dice) + cw * cons + cfg.u_weight * (fecl + uncl)
+    gnorm, clipped = clip_grad_norm(avg, cfg.max_grad_norm)
+    for st in states:
+        params = {k: st.student[k] for k in clipped}
+        sgd_step(params, clipped, st.momentum, st.lr if st.lr is not None else cfg.base_lr, cfg.momentum, cfg.weight_decay)
+        st.student.update(params)
+        t_params = {k: st.teacher[k] for k in names}
+        ema_update(t_params, {k: st.student[k] for k in names}, cfg.ema_decay, st.iter_num)
+        st.teacher.update(t_params)
+        st.iter_num += 1
+    return {"loss": total, "ce": ce, "dice": dice, "cons": cons, "fecl": fecl, "uncl": uncl, "grad_norm": gnorm, "grads": avg}

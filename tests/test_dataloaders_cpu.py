@@ -41,3 +41,17 @@ def test_transforms_numpy_and_tensor_agree():
     np.random.seed(5)
     n1 = D.RandomNoise()({"image": img, "label": lab})["image"]
     assert np.abs(n1 - img).max() <= 0.2 + 1e-6
+
+
+def test_sagittal_to_axial():
+    rng = np.random.default_rng(1)
+    img = rng.standard_normal((6, 5, 4)).astype(np.float32)
+    lab = (rng.random((6, 5, 4)) > 0.5).astype(np.uint8)
+    a = D.SagittalToAxial()({"image": img, "label": lab})
+    assert a["image"].shape == (4, 5, 6) and a["image"][1, 2, 3] == img[3, 2, 1] and a["label"][0, 4, 5] == lab[5, 4, 0]
+    b = D.SagittalToAxial()({"image": torch.from_numpy(img), "label": torch.from_numpy(lab)})
+    np.testing.assert_array_equal(a["image"], b["image"].numpy())
+    np.testing.assert_array_equal(a["label"], b["label"].numpy())
+    import pytest
+    with pytest.raises(ValueError):
+        D.SagittalToAxial()({"image": img, "label": lab[:5]})

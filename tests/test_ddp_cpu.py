@@ -131,3 +131,35 @@ def test_ddp_exchange_equals_global_batch_gradient():
         mp.spawn(_worker, args=(init_file, out_file), nprocs=WORLD, join=True)
         got = torch.load(out_file)["grad"]
     np.testing.assert_allclose(got.numpy(), ref_flat.numpy(), rtol=1e-4, atol=1e-6)
+
+
+def test_ddp_oracle_step_consistency():
+    """oracle.step.ddp_train_step (the emulation the 2-rank GPU test is checked against): with one rank it IS train_step; with two
+    ranks and the feature losses off (no per-rank BatchNorm in play) it equals train_step on the global batch."""
+    from dycon_paper_replication_amd.synthetic import make_batch
+    from oracle import nets as ON
+    from oracle import step as OS
+    vol, lab, noise = make_batch(9, 4, (32, 32, 32))                   # global batch [lab0, lab1 | unl0, unl1]
+    mk = lambda: OS.StepState(student=ON.make_vnet_params(5), teacher=ON.make_vnet_params(6))  # noqa: E731
+    keys = ("loss", "ce", "dice", "cons", "fecl", "uncl")
+    # one rank, everything on
+    a, b = mk(), mk()
+    cfg = OS.StepConfig(net_type="vnet", labeled_bs=2)
+    ra = OS.train_step(cfg, a, vol, lab, noise, 2.5, 300)
+    rb = OS.ddp_train_step(cfg, [b], [(vol, lab, noise)], 2.5, 300)
+    np.testing.assert_allclose([float(ra[k]) for k in keys], [float(rb[k]) for k in keys], rtol=1e-5, atol=1e-7)
+    for k in ("block_one.conv.0.weight", "block_five.conv.3.weight", "projection.3.weight"):
+        np.testing.assert_allclose(a.student[k].numpy(), b.student[k].numpy(), rtol=1e-5, atol=1e-7, err_msg=k)
+    # two ranks, u_weight = 0
+    g = mk()
+    cfg_g = OS.StepConfig(net_type="vnet", labeled_bs=2, u_weight=0.0, base_lr=0.02)
+    rg = OS.train_step(cfg_g, g, vol, lab, noise, 2.5, 0)
+    states = [mk(), mk()]
+    cfg_r = OS.StepConfig(net_type="vnet", labeled_bs=1, u_weight=0.0, base_lr=0.02)
+    shards = [(vol[[r, 2 + r]], lab[[r, 2 + r]], noise[[r, 2 + r]]) for r in range(2)]
+    rr = OS.ddp_train_step(cfg_r, states, shards, 2.5, 0)
+    np.testing.assert_allclose([float(rg[k]) for k in ("ce", "dice", "cons")], [float(rr[k]) for k in ("ce", "dice", "cons")], rtol=1e-5)
+    assert float(rr["grad_norm"]) == pytest.approx(float(rg["grad_norm"]), rel=1e-4)
+    for k in ("block_one.conv.0.weight", "block_nine.conv.0.weight", "out_conv.weight"):
+        np.testing.assert_allclose(states[0].student[k].numpy(), g.student[k].numpy(), rtol=1e-4, atol=1e-6, err_msg=k)
+        assert torch.equal(states[0].student[k], states[1].student[k])

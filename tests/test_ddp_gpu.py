@@ -1,7 +1,12 @@
-"""GPU, 2 ranks sharing the one GPU of the test box (gloo rendezvous; RCCL refuses duplicate devices): the sharded DyCON step
-(bucketed gradient all-reduce overlapped with the backward, all-reduced Dice sums, x world pre-scaling, 1/world folded into the
-SGD kernel) reproduces the single-process step on the global batch.  u_weight = 0 switches FeCL/UnCL off so that the per-rank
-BatchNorm statistics of the projection head (per-replica in the reference's DataParallel too) do not enter the comparison."""
+"""GPU, 2 ranks sharing the one GPU of the test box (gloo rendezvous; RCCL refuses duplicate devices): the sharded DyCON step --
+bucketed gradient all-reduce overlapped with the backward, all-reduced Dice / FeCL accumulators, x world pre-scaling, 1/world folded
+into the SGD kernel.
+
+* u_weight = 0: equals the single-process HIP step on the global batch (no per-rank BatchNorm in play).
+* u_weight = 0.5 (FeCL + UnCL ON, the default): against oracle.step.ddp_train_step, the CPU emulation in which every rank forwards
+  its own shard (per-rank BatchNorm statistics in the projection head, as the reference's DataParallel replicas) and the 16 + 4
+  accumulators are summed over ranks -- exercises fecl_finalize(rows = B*world*N) and the x world cross-branch gradient.
+* replay == eager under a process group (the recorded step contains the collectives)."""
 import os
 import tempfile
 
@@ -11,43 +16,67 @@ import torch
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
+KEYS = ("loss", "ce", "dice", "cons", "fecl", "uncl")
 
 
-def _cfg():
+def _cfg(u_weight=0.0, dtype=torch.float32, replay=True):
     from dycon_paper_replication_amd.trainer import TrainConfig
-    return TrainConfig(model="vnet", labeled_bs=1, batch_size=2, dtype=torch.float32, seed=5, u_weight=0.0, base_lr=0.01)
+    return TrainConfig(model="vnet", labeled_bs=1, batch_size=2, dtype=dtype, seed=5, u_weight=u_weight, base_lr=0.01, replay=replay)
 
 
-def _worker(rank, init_file, out_file):
+def _worker(rank, init_file, out_file, mode):
     import torch.distributed as dist
     from dycon_paper_replication_amd.engine import DropoutSpec
     from dycon_paper_replication_amd.synthetic import make_batch
     from dycon_paper_replication_amd.trainer import DyconTrainer
+    from oracle import nets as ON
     dist.init_process_group("gloo", init_method=f"file://{init_file}", rank=rank, world_size=2)
     torch.cuda.set_device(0)
     vol, lab, noise = make_batch(9, 4, (32, 32, 32))          # global batch [lab0, lab1 | unl0, unl1]
     idx = [rank, 2 + rank]
-    tr = DyconTrainer(_cfg(), DEV, process_group=dist.group.WORLD)
-    assert len(tr.buckets) >= 2
     off = DropoutSpec("off")
-    for _ in range(2):
-        out = tr.step(vol[idx].to(DEV), lab[idx].to(DEV), noise=noise[idx].to(DEV), s_drop=off, t_drop=off)
+    res = {}
+    if mode in ("global", "fecl"):
+        init = dict(student_init=ON.make_vnet_params(5), teacher_init=ON.make_vnet_params(6)) if mode == "fecl" else {}
+        tr = DyconTrainer(_cfg(0.5 if mode == "fecl" else 0.0), DEV, process_group=dist.group.WORLD, **init)
+        assert len(tr.buckets) >= 2
+        rows = []
+        for _ in range(2):
+            out = tr.step(vol[idx].to(DEV), lab[idx].to(DEV), noise=noise[idx].to(DEV), s_drop=off, t_drop=off, epoch=300, beta=2.5)
+            rows.append([float(out[k]) for k in KEYS] + [float(out["grad_sumsq"].sqrt())])
+        res = {"p": tr.flat_p.cpu(), "t": tr.flat_t.cpu(), "rows": rows, "names": tr.names,
+               "params": {k: tr.p[k].cpu() for k in ("block_one.conv.0.weight", "block_five.conv.3.weight", "projection.3.weight",
+                                                     "projection.0.weight", "out_conv.weight")}}
+    else:   # replay vs eager, bf16, on-device Philox randomness, changing batches
+        batches = [make_batch(500 + i, 4, (32, 32, 32)) for i in range(7)]
+        for replay in (False, True):
+            tr = DyconTrainer(_cfg(0.5, torch.bfloat16, replay), DEV, process_group=dist.group.WORLD)
+            losses = []
+            for v, l, _ in batches:
+                out = tr.step(v[idx].to(DEV), l[idx].to(DEV))
+                losses.append([float(out[k]) for k in KEYS])
+            assert (tr._rp is not None) == replay and tr.iter_num == 7
+            res[replay] = (np.array(losses), tr.flat_p.cpu(), tr.flat_t.cpu())
     torch.cuda.synchronize()
     if rank == 0:
-        torch.save({"p": tr.flat_p.cpu(), "t": tr.flat_t.cpu(), "loss": float(out["loss"]), "dice": float(out["dice"])}, out_file)
+        torch.save(res, out_file)
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_two_rank_step_equals_global_batch_step():
+def _run(mode):
     import torch.multiprocessing as mp
+    with tempfile.TemporaryDirectory() as d:
+        init_file, out_file = os.path.join(d, "init"), os.path.join(d, "out.pt")
+        mp.spawn(_worker, args=(init_file, out_file, mode), nprocs=2, join=True)
+        return torch.load(out_file, weights_only=False)
+
+
+def test_two_rank_step_equals_global_batch_step():
     from dycon_paper_replication_amd.engine import DropoutSpec
     from dycon_paper_replication_amd.synthetic import make_batch
     from dycon_paper_replication_amd.trainer import DyconTrainer
-    with tempfile.TemporaryDirectory() as d:
-        init_file, out_file = os.path.join(d, "init"), os.path.join(d, "out.pt")
-        mp.spawn(_worker, args=(init_file, out_file), nprocs=2, join=True)
-        got = torch.load(out_file)
+    got = _run("global")
     cfg = _cfg()
     cfg.labeled_bs, cfg.batch_size = 2, 4
     cfg.base_lr = 0.02            # the 2-rank run scales LR x world (train_DyCON_BraTS19.py:108-110)
@@ -55,8 +84,36 @@ def test_two_rank_step_equals_global_batch_step():
     vol, lab, noise = make_batch(9, 4, (32, 32, 32))
     off = DropoutSpec("off")
     for _ in range(2):
-        out = tr.step(vol.to(DEV), lab.to(DEV), noise=noise.to(DEV), s_drop=off, t_drop=off)
-    assert got["loss"] == pytest.approx(float(out["loss"]), rel=1e-4)
-    assert got["dice"] == pytest.approx(float(out["dice"]), rel=1e-4)
+        out = tr.step(vol.to(DEV), lab.to(DEV), noise=noise.to(DEV), s_drop=off, t_drop=off, epoch=300, beta=2.5)
+    assert got["rows"][-1][0] == pytest.approx(float(out["loss"]), rel=1e-4)
+    assert got["rows"][-1][2] == pytest.approx(float(out["dice"]), rel=1e-4)
     np.testing.assert_allclose(got["p"].numpy(), tr.flat_p.cpu().numpy(), rtol=2e-4, atol=2e-6)
     np.testing.assert_allclose(got["t"].numpy(), tr.flat_t.cpu().numpy(), rtol=2e-4, atol=2e-6)
+
+
+def test_two_rank_step_with_fecl_vs_ddp_oracle():
+    """FeCL / UnCL on (u_weight = 0.5): the all_reduce of the FeCL accumulators, fecl_finalize with world > 1 and the x world
+    scaling of the cross-branch gradient, against the CPU emulation of the data-parallel step (run in DOUBLE: the true values)."""
+    from dycon_paper_replication_amd.synthetic import make_batch
+    from oracle import nets as ON
+    from oracle import step as OS
+    got = _run("fecl")
+    dbl = lambda p: {k: (v.double() if v.is_floating_point() else v) for k, v in p.items()}  # noqa: E731
+    states = [OS.StepState(student=dbl(ON.make_vnet_params(5)), teacher=dbl(ON.make_vnet_params(6))) for _ in range(2)]
+    cfg = OS.StepConfig(net_type="vnet", labeled_bs=1, u_weight=0.5, base_lr=0.02)
+    vol, lab, noise = make_batch(9, 4, (32, 32, 32))
+    shards = [(vol[[r, 2 + r]].double(), lab[[r, 2 + r]], noise[[r, 2 + r]].double()) for r in range(2)]
+    for step in range(2):
+        ref = OS.ddp_train_step(cfg, states, shards, 2.5, 300)
+        exp = [float(ref[k]) for k in KEYS] + [float(ref["grad_norm"])]
+        np.testing.assert_allclose(got["rows"][step], exp, rtol=1e-4, atol=1e-6, err_msg=f"step {step}")
+        assert exp[4] > 0.1          # FeCL really is in play
+    for k, v in got["params"].items():
+        np.testing.assert_allclose(v.numpy(), states[0].student[k].numpy(), rtol=1e-4, atol=2e-6, err_msg=k)
+
+
+def test_two_rank_replay_equals_eager():
+    got = _run("replay")
+    np.testing.assert_allclose(got[True][0], got[False][0], rtol=1e-5, atol=1e-6)
+    for a, b in zip(got[True][1:], got[False][1:]):
+        assert float((a - b).abs().max()) <= 1e-6 * float(b.abs().max())

@@ -16,9 +16,23 @@ DEV = "cuda:0"
 T = torch.from_numpy
 
 
+def _double(p):
+    return {k: (v.double() if v.is_floating_point() else v) for k, v in p.items()}
+
+
 def _stats(t):
     t = t.detach().double().cpu()
     return np.array([t.sum().item(), t.abs().sum().item(), (t * t).sum().item()])
+
+
+def within_budget(hip, ref32, ref64, what, floor=1e-4):
+    """|hip - ref64| <= the north-star's 1e-4 (abs + rel), AND <= 2 |ref32 - ref64| + 1e-6 in the max norm -- or, where the
+    reference's own fp32 run is further than `floor` from its fp64 twin, at least within that measured budget."""
+    hip, ref32, ref64 = (np.asarray(a, dtype=np.float64) for a in (hip, ref32, ref64))
+    e_hip, e_ref = np.abs(hip - ref64).max(), np.abs(ref32 - ref64).max()
+    print(f"{what}: |hip-ref64| {e_hip:.3e}, reference's own |ref32-ref64| {e_ref:.3e}")
+    assert e_hip <= 2 * e_ref + 1e-6, f"{what}: HIP error {e_hip:.3e} exceeds twice the reference's own fp32 error {e_ref:.3e}"
+    np.testing.assert_allclose(hip, ref64, rtol=floor, atol=floor, err_msg=what)
 
 
 def build(kind, seed, dtype=torch.float32):
@@ -52,13 +66,17 @@ def test_full_net_fp32_vs_reference(kind):
     logits, feats, _ = eng.forward(xd, training=True, record=True)
     lo = logits.cpu().permute(0, 4, 1, 2, 3)
     fe = feats.cpu().permute(0, 4, 1, 2, 3)
-    np.testing.assert_allclose(lo[..., ::2, ::2, ::2].numpy(), g[f"{kind}.logits_sub"], rtol=1e-4, atol=1e-4)
-    np.testing.assert_allclose(_stats(lo), g[f"{kind}.logits_stats"], rtol=1e-4)
-    np.testing.assert_allclose(fe.numpy(), g[f"{kind}.feats"], rtol=1e-4, atol=1e-4)
+    # fp64 footing (the ".f64" keys are the same reference modules run in double): the HIP path must be within the north-star's
+    # 1e-4 of the TRUE value and within twice the reference's own fp32 error of it
+    within_budget(lo[..., ::2, ::2, ::2].numpy(), g[f"{kind}.logits_sub"], g[f"{kind}.logits_sub.f64"], "logits")
+    within_budget(fe.numpy(), g[f"{kind}.feats"], g[f"{kind}.feats.f64"], "feats")
+    np.testing.assert_allclose(_stats(lo), g[f"{kind}.logits_stats.f64"], rtol=1e-4)
     eng.backward(r1.permute(0, 2, 3, 4, 1).contiguous().to(DEV), r2.permute(0, 2, 3, 4, 1).contiguous().to(DEV))
     torch.cuda.synchronize()
     names = list(g[f"{kind}.grad_names"])
-    refs = dict(zip(names, g[f"{kind}.grad_stats"]))
+    refs = dict(zip(names, g[f"{kind}.grad_stats.f64"]))
+    refs32 = dict(zip(names, g[f"{kind}.grad_stats"]))
+    worst = (0.0, None, 0.0)
     for k, ref in refs.items():
         if k.startswith("final."):
             assert not ref.any() and torch.isnan(eng.g[k]).all()   # no gradient reaches the discarded sdf head
@@ -68,14 +86,20 @@ def test_full_net_fp32_vs_reference(kind):
         one_channel_groups = kind == "unet" or eng.p[k].shape[0] == 16 or k.startswith("projection.")
         if k.endswith(".bias") and eng.p[w].dim() == 5 and not k.startswith("out_conv") and one_channel_groups:
             # a conv bias in front of a per-channel normalisation (InstanceNorm / BatchNorm / GroupNorm with one
-            # channel per group) has an analytically ZERO gradient: both sides hold round-off noise only
+            # channel per group) has an analytically ZERO gradient (the fp64 twin holds ~1e-13): round-off noise only
             assert got[1] <= 1e-4 * refs[w][1] + 2e-2, (k, got, ref)
             continue
-        # statistics are (sum, sum|.|, sum .^2): the plain sum cancels heavily, so it is held relative to sum|.|.
-        # This random-weighted objective drives gradients of 1e5 through 40 layers; the realistic-loss traces in
-        # test_trainer_gpu.py hold gradient norm and updated parameters to 1e-4.
-        assert abs(got[0] - ref[0]) <= 3e-3 * ref[1] + 5e-3, (k, got, ref)
-        np.testing.assert_allclose(got[1:], ref[1:], rtol=3e-3, atol=5e-3, err_msg=k)
+        # statistics are (sum, sum|.|, sum .^2): the plain sum cancels heavily, so it is held relative to sum|.|.  This
+        # random-weighted objective drives gradients of 1e5 through 40 layers; bound = the north-star's 1e-4 or twice the
+        # reference's own fp32 error against its fp64 twin, whichever is larger (it is the latter for the deep encoder weights)
+        e32 = np.abs(refs32[k] - ref)
+        bud = [max(1e-4 * ref[1], 2 * e32[0]) + 1e-6, max(1e-4 * ref[1], 2 * e32[1]) + 1e-6, max(1e-4 * ref[2], 2 * e32[2]) + 1e-6]
+        err = np.abs(got - ref)
+        for j in range(3):
+            if err[j] / bud[j] > worst[0]:
+                worst = (err[j] / bud[j], k, err[j] / (ref[1] if j < 2 else ref[2]))
+        assert (err <= bud).all(), (k, got, ref, refs32[k])
+    print(f"full net {kind}: worst gradient statistic at {worst[0]:.2f} of its budget ({worst[1]}, rel err {worst[2]:.2e})")
 
 
 @pytest.mark.parametrize("kind", ["vnet", "unet"])
@@ -105,11 +129,13 @@ def test_vnet_dropout3d_masks_vs_oracle():
     names = list(ON.trainable(p_all))
     leaves = {k: p_all[k].clone().requires_grad_(True) for k in names}
     _, lo_ref, fe_ref = ON.vnet_forward(x, {**p_all, **leaves}, drop5=m5, drop9=m9)
+    with torch.no_grad():
+        _, lo64, fe64 = ON.vnet_forward(x.double(), _double(p_all), drop5=m5.double(), drop9=m9.double())
     grads = torch.autograd.grad((lo_ref * r1).sum() + fe_ref.sum(), [leaves[k] for k in names])
     spec = DropoutSpec("mask", masks={"drop5": m5.to(DEV), "drop9": m9.to(DEV)})
     logits, feats, _ = eng.forward(x.permute(0, 2, 3, 4, 1).contiguous().to(DEV), dropout=spec)
-    np.testing.assert_allclose(logits.cpu().permute(0, 4, 1, 2, 3).numpy(), lo_ref.detach().numpy(), rtol=2e-4, atol=2e-4)
-    np.testing.assert_allclose(feats.cpu().permute(0, 4, 1, 2, 3).numpy(), fe_ref.detach().numpy(), rtol=2e-4, atol=2e-4)
+    within_budget(logits.cpu().permute(0, 4, 1, 2, 3).numpy(), lo_ref.detach().numpy(), lo64.numpy(), "logits")
+    within_budget(feats.cpu().permute(0, 4, 1, 2, 3).numpy(), fe_ref.detach().numpy(), fe64.numpy(), "feats")
     eng.backward(r1.permute(0, 2, 3, 4, 1).contiguous().to(DEV), torch.ones_like(feats))
     for k in ("block_nine.conv.0.weight", "block_five.conv.6.weight", "block_one.conv.1.weight", "out_conv.weight"):
         ref = dict(zip(names, grads))[k]
@@ -126,10 +152,11 @@ def test_vnet_isles_geometry_vs_oracle():
     x = torch.randn(1, 1, 112, 112, 80)
     with torch.no_grad():
         _, lo_ref, fe_ref = ON.vnet_forward(x, p_all, scale_factor=4)
+        _, lo64, fe64 = ON.vnet_forward(x.double(), _double(p_all), scale_factor=4)
     logits, feats, _ = eng.forward(x.permute(0, 2, 3, 4, 1).contiguous().to(DEV), record=False)
     assert tuple(feats.shape) == (1, 28, 28, 20, 256)
-    np.testing.assert_allclose(logits.cpu().permute(0, 4, 1, 2, 3).numpy(), lo_ref.numpy(), rtol=3e-4, atol=3e-4)
-    np.testing.assert_allclose(feats.cpu().permute(0, 4, 1, 2, 3).numpy(), fe_ref.numpy(), rtol=3e-4, atol=3e-4)
+    within_budget(logits.cpu().permute(0, 4, 1, 2, 3).numpy(), lo_ref.numpy(), lo64.numpy(), "logits")
+    within_budget(feats.cpu().permute(0, 4, 1, 2, 3).numpy(), fe_ref.numpy(), fe64.numpy(), "feats")
 
 
 @pytest.mark.parametrize("kind", ["vnet", "unet"])
@@ -142,10 +169,11 @@ def test_pancreas_geometry_vs_oracle(kind):
     fwd = ON.vnet_forward if kind == "vnet" else ON.unet_forward
     with torch.no_grad():
         _, lo_ref, fe_ref = fwd(x, p_all, scale_factor=2)
+        _, lo64, fe64 = fwd(x.double(), _double(p_all), scale_factor=2)
     logits, feats, _ = eng.forward(x.permute(0, 2, 3, 4, 1).contiguous().to(DEV), record=False)
     assert tuple(feats.shape) == (1, 14, 14, 12, 256)
-    np.testing.assert_allclose(logits.cpu().permute(0, 4, 1, 2, 3).numpy(), lo_ref.numpy(), rtol=3e-4, atol=3e-4)
-    np.testing.assert_allclose(feats.cpu().permute(0, 4, 1, 2, 3).numpy(), fe_ref.numpy(), rtol=3e-4, atol=3e-4)
+    within_budget(logits.cpu().permute(0, 4, 1, 2, 3).numpy(), lo_ref.numpy(), lo64.numpy(), "logits")
+    within_budget(feats.cpu().permute(0, 4, 1, 2, 3).numpy(), fe_ref.numpy(), fe64.numpy(), "feats")
 
 
 def test_bf16_step_gradient_tracks_fp32_isles_geometry():
@@ -170,3 +198,40 @@ def test_bf16_step_gradient_tracks_fp32_isles_geometry():
     ratio = float(a.norm() / b.norm())
     assert cos > 0.98 and 0.9 < ratio < 1.1, (cos, ratio)
     np.testing.assert_allclose(losses[torch.bfloat16], losses[torch.float32], rtol=3e-2, atol=3e-3)
+
+
+@pytest.mark.parametrize("norm", ["none", "batchnorm", "instancenorm"])
+def test_vnet_other_normalizations_vs_oracle(norm):
+    """The V-Net with the reference's other normalisation options (VNet.py:17-24; 'none' is what the reference factory would
+    build, VNet.py:146): forward and parameter gradients at 32^3 against the oracle (fp32 and fp64 twin)."""
+    from dycon_paper_replication_amd.engine import net_buffers
+    p_all = ON.make_vnet_params(9, normalization=norm)
+    spec = param_spec("vnet", normalization=norm)
+    assert list(spec) == list(ON.trainable(p_all))
+    params = {k: p_all[k].to(DEV).contiguous() for k in spec}
+    grads = {k: torch.full_like(v, float("nan")) for k, v in params.items()}
+    bufs = {}
+    for k, shp in net_buffers("vnet", norm).items():
+        bufs[k] = (torch.zeros(shp, dtype=torch.long) if k.endswith("tracked") else
+                   (torch.ones(shp) if k.endswith("var") else torch.zeros(shp))).to(DEV)
+    eng = Engine("vnet", params, grads, bufs, dtype=torch.float32, normalization=norm)
+    torch.manual_seed(3)
+    scale = 0.2 if norm == "none" else 1.0            # un-normalised He-initialised stack: keep the activations O(1)
+    x = torch.randn(2, 1, 32, 32, 32) * scale
+    r1 = torch.randn(2, 2, 32, 32, 32)
+    names = list(ON.trainable(p_all))
+    leaves = {k: p_all[k].clone().requires_grad_(True) for k in names}
+    _, lo_ref, fe_ref = ON.vnet_forward(x, {**p_all, **leaves}, normalization=norm)
+    gr = dict(zip(names, torch.autograd.grad((lo_ref * r1).sum() + fe_ref.sum(), [leaves[k] for k in names])))
+    with torch.no_grad():
+        _, lo64, fe64 = ON.vnet_forward(x.double(), _double(p_all), normalization=norm)
+    logits, feats, _ = eng.forward(x.permute(0, 2, 3, 4, 1).contiguous().to(DEV), training=True, record=True)
+    within_budget(logits.cpu().permute(0, 4, 1, 2, 3).numpy(), lo_ref.detach().numpy(), lo64.numpy(), "logits")
+    within_budget(feats.cpu().permute(0, 4, 1, 2, 3).numpy(), fe_ref.detach().numpy(), fe64.numpy(), "feats")
+    eng.backward(r1.permute(0, 2, 3, 4, 1).contiguous().to(DEV), torch.ones_like(feats))
+    for k in ("block_nine.conv.0.weight", "block_five.conv.0.weight", "block_one.conv.0.weight", "out_conv.weight",
+              "block_five_up.conv.0.weight", "block_two_dw.conv.0.weight") + (("block_three.conv.1.weight",) if norm == "batchnorm" else ()):
+        got, ref = eng.g[k].cpu(), gr[k]
+        assert (got - ref).abs().max() <= 1e-3 * ref.abs().max() + 1e-6, (k, float((got - ref).abs().max()), float(ref.abs().max()))
+    if norm == "batchnorm":      # running statistics updated with momentum 0.1 (nn.BatchNorm3d defaults)
+        assert float(bufs["block_one.conv.1.running_mean"].abs().max()) > 0 and int(bufs["block_one.conv.1.num_batches_tracked"]) == 1

@@ -1,6 +1,8 @@
 """GPU parity tests, op level: every HIP kernel (called through the C ABI) against the oracle /
 the golden fixtures from the reference.  fp32 storage: tolerance 1e-4 (north-star); bf16: loose.
 """
+import zlib
+
 import numpy as np
 import pytest
 import torch
@@ -76,7 +78,7 @@ CONV_CASES = [
 @pytest.mark.parametrize("kind,cin,cout,sp", CONV_CASES)
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_conv(kind, cin, cout, sp, dtype):
-    rng = np.random.default_rng(hash((kind, cin, cout)) % 2**31)
+    rng = np.random.default_rng(zlib.crc32(repr((kind, cin, cout)).encode()))   # (hash() of a str is salted per process)
     B = 2
     k = {"k3": 3, "k2s2": 2, "deconv": 2, "1x1": 1}[kind]
     wshape = (cin, cout, k, k, k) if kind == "deconv" else (cout, cin, k, k, k)
@@ -444,3 +446,35 @@ def test_fecl_isles_size_vs_rowblock_oracle():
     l16, _ = ops.fecl_fwd(*args(f.to(DEV).bfloat16(), t.to(DEV).bfloat16()))
     ref16, _ = OL.fecl_rowblocks(f.bfloat16().float(), mask.view(B, 1, N), t.bfloat16().float(), epoch, 0.6, 2.0, True, 1500, 1.0, block=2048)
     close(l16[0], ref16, 5e-4, 1e-6)
+
+
+@pytest.mark.parametrize("norm", ["groupnorm", "none", "instancenorm", "batchnorm"])
+def test_vnet_convblock_reference_fixtures(norm):
+    """VNet.ConvBlock(2, 16, co, normalization=...) of the REFERENCE (VNet.py:5-31; fixture vnet_layers.npz, all four
+    normalisations incl. the factory default 'none' and 'batchnorm'): conv -> [norm] -> ReLU twice through the engine's layer
+    calls, forward, data gradient and every parameter gradient against the reference's outputs."""
+    g = load_golden("vnet_layers")
+    pre = f"convblock_{norm}."
+    st = 2 if norm == "none" else 3
+    nk = {"groupnorm": "gn", "instancenorm": "in", "batchnorm": "bn", "none": "none"}[norm]
+    params = {k[len(pre) + 2:]: T(g[k]) for k in g.files if k.startswith(pre + "p.") and "running" not in k and "num_batches" not in k}
+    e = mini_engine(params)
+    e.buf = {}
+    x = T(g[pre + "x"])
+    xd = nd(x)
+    t = xd
+    for i in range(2):
+        t = e._conv(f"conv.{st * i}", t, "k3")
+        t = e._norm(f"conv.{st * i + 1}", t, nk)
+    y = t.clone()
+    e.G[id(t)] = nd(T(g[pre + "r"]))
+    for fn in reversed(e.tape):
+        fn()
+    close(nc(y), g[pre + "y"], 1e-4, 1e-5, "y")
+    close(nc(e.G[id(xd)]), g[pre + "gx"], 1e-4, 1e-5, "gx")
+    for k in params:
+        ref = g[pre + "g." + k]
+        if k.endswith(".bias") and params[k[:-4] + "weight"].dim() == 5 and norm in ("instancenorm", "batchnorm"):
+            assert float(e.g[k].abs().max()) <= 1e-4 * float(np.abs(g[pre + "g." + k[:-4] + "weight"]).max())   # analytically zero
+            continue
+        close(e.g[k], ref, 1e-4, 1e-4 * float(np.abs(ref).max()), k)
