@@ -13,6 +13,8 @@
 //
 // fp32 storage uses v_mfma_f32_16x16x4_f32 (exact fp32 FMA chain: the 1e-4 parity mode),
 // bf16 storage uses v_mfma_f32_16x16x32_bf16 (fp32 accumulate).
+#include <stdlib.h>
+
 #include "common.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -407,8 +409,17 @@ constexpr int CL_HZ = CL_TZ + 2, CL_HY = CL_TY + 2, CL_HX = CL_TX + 2;
 constexpr int CL_NH = CL_HZ * CL_HY * CL_HX;     // 600 halo voxels
 constexpr int CL_NV = CL_TZ * CL_TY * CL_TX;     // 256 voxels = 16 m-tiles
 
+#ifndef CL_LB2
+#define CL_LB2 1                                   // min workgroups per CU the register allocation must allow (experiments: 2)
+#endif
+#ifndef CL_NTB64
+#define CL_NTB64 4                                 // n-tiles per workgroup for 64-wide output blocks (experiments: 2)
+#endif
+#ifndef CL_BPREF
+#define CL_BPREF 0                                 // B fragments read one k-step ahead of their MFMAs
+#endif
 template <int CK, int NTB, int WM>
-__global__ __launch_bounds__(256) void conv_k3_lds_kernel(const bf16* __restrict__ X, const bf16* __restrict__ Wf,
+__global__ __launch_bounds__(256, CL_LB2) void conv_k3_lds_kernel(const bf16* __restrict__ X, const bf16* __restrict__ Wf,
                                                           const float* __restrict__ bias, bf16* __restrict__ Y, int B, int D, int H,
                                                           int W, int Cin, int Cout, int NT, int tilesZ, int tilesY, int tilesX,
                                                           int accumulate) {
@@ -541,6 +552,28 @@ __global__ __launch_bounds__(256) void conv_k3_lds_kernel(const bf16* __restrict
 #pragma unroll
             for (int m = 0; m < MTW; ++m) afr[0][m] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(Xh + vbase[m] + toff));
         }
+#if CL_BPREF
+        bf16x8 bfr[2][NTW];
+#pragma unroll
+        for (int j = 0; j < NTW; ++j)
+            bfr[0][j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(Bs + ((wn * NTW + j) * 64 + lane) * 8));
+#pragma unroll
+        for (int u = 0; u < GRP; ++u) {
+            if (u + 1 < GRP) {
+                const int toff = tap_off(g * GRP + u + 1);
+#pragma unroll
+                for (int j = 0; j < NTW; ++j)
+                    bfr[(u + 1) & 1][j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(Bs + (((u + 1) * NTB + wn * NTW + j) * 64 + lane) * 8));
+#pragma unroll
+                for (int m = 0; m < MTW; ++m)
+                    afr[(u + 1) & 1][m] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(Xh + vbase[m] + toff));
+            }
+#pragma unroll
+            for (int m = 0; m < MTW; ++m)
+#pragma unroll
+                for (int j = 0; j < NTW; ++j) acc[m][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[u & 1][m], bfr[u & 1][j], acc[m][j], 0, 0, 0);
+        }
+#else
 #pragma unroll
         for (int u = 0; u < GRP; ++u) {
             bf16x8 bfr[NTW];
@@ -558,6 +591,7 @@ __global__ __launch_bounds__(256) void conv_k3_lds_kernel(const bf16* __restrict
 #pragma unroll
                 for (int j = 0; j < NTW; ++j) acc[m][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[u & 1][m], bfr[j], acc[m][j], 0, 0, 0);
         }
+#endif
         if (has_next) {
             __syncthreads();                 // phase p fully consumed
             store_b();
@@ -1486,24 +1520,35 @@ __global__ __launch_bounds__(256) void head_1x1_bwd_kernel(const float* __restri
     }
 }
 
-// out[map(i)] = sum_p part[p*L + i], i = (t*Cin + ci)*Cout + co, map = t*s_t + ci*s_c + co*s_n
-// 256 threads = 32 outputs x 8 partial lanes (ordered, deterministic): short dependent chains even for P = 256
-__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ part, int P, int L, float* __restrict__ out,
-                                                              int Cin, int Cout, long long s_t, long long s_c, long long s_n) {
+// ordered sum over the P partial slabs of a weight-gradient launch:  out[t*s_t + ci*s_c + co*s_n] = sum_p part[p][(t, ci, co)].
+// One launch serves up to two jobs (the weight slabs and the bias-gradient partials of the same wgrad call): blocks
+// [0, nb0) belong to job 0, the rest to job 1.
+struct ReduceJob { const float* part; float* out; int P, L, Cin, Cout; long long s_t, s_c, s_n; };
+__global__ __launch_bounds__(256) void reduce_partials_kernel(ReduceJob j0, ReduceJob j1, int nb0) {
     __shared__ float sm[8][33];
+    const bool second = (int)blockIdx.x >= nb0;
+    const ReduceJob& jb = second ? j1 : j0;
+    const int bid = second ? blockIdx.x - nb0 : blockIdx.x;
     const int o = threadIdx.x & 31, pl = threadIdx.x >> 5;
-    const int i = blockIdx.x * 32 + o;
-    float s = 0.f;
-    if (i < L)
-        for (int p = pl; p < P; p += 8) s += part[(long long)p * L + i];
-    sm[pl][o] = s;
+    const int i = bid * 32 + o;
+    const int L = jb.L, P = jb.P;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;          // four independent chains: the loads of a thread are 8*L floats apart
+    if (i < L) {
+        const float* pp = jb.part + i;
+        int p = pl;
+        for (; p + 24 < P; p += 32) {
+            s0 += pp[(long long)p * L]; s1 += pp[(long long)(p + 8) * L]; s2 += pp[(long long)(p + 16) * L]; s3 += pp[(long long)(p + 24) * L];
+        }
+        for (; p < P; p += 8) s0 += pp[(long long)p * L];
+    }
+    sm[pl][o] = (s0 + s1) + (s2 + s3);
     __syncthreads();
     if (pl == 0 && i < L) {
         float tot = 0.f;
 #pragma unroll
         for (int k = 0; k < 8; ++k) tot += sm[k][o];
-        const int co = i % Cout, ci = (i / Cout) % Cin, t = i / (Cout * Cin);
-        out[t * s_t + ci * s_c + co * s_n] = tot;
+        const int co = i % jb.Cout, ci = (i / jb.Cout) % jb.Cin, t = i / (jb.Cout * jb.Cin);
+        jb.out[t * jb.s_t + ci * jb.s_c + co * jb.s_n] = tot;
     }
 }
 
@@ -1559,7 +1604,7 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ X, fl
     }
 }
 
-// small-L reduction: one block per output, 256 lanes over the partials (bias gradients: L = Cout <= 512)
+// small-L reduction: one block per output, 256 lanes over the partials (column sums: L = C <= 512, P up to 2048)
 __global__ __launch_bounds__(256) void reduce_partials_small_kernel(const float* __restrict__ part, int P, int L, float* __restrict__ out,
                                                                     int Cin, int Cout, long long s_t, long long s_c, long long s_n) {
     __shared__ float red[17];
@@ -1574,9 +1619,15 @@ __global__ __launch_bounds__(256) void reduce_partials_small_kernel(const float*
 }
 
 static void launch_reduce_partials(const float* part, int P, int L, float* out, int Cin, int Cout, long long s_t, long long s_c,
-                                   long long s_n, dycon_stream_t stream) {
-    if (L <= 512 && P > 64) reduce_partials_small_kernel<<<L, 256, 0, stream>>>(part, P, L, out, Cin, Cout, s_t, s_c, s_n);
-    else reduce_partials_kernel<<<cdiv(L, 32), 256, 0, stream>>>(part, P, L, out, Cin, Cout, s_t, s_c, s_n);
+                                   long long s_n, dycon_stream_t stream, const float* bias_part = nullptr, float* bias_out = nullptr) {
+    if (!bias_part && L <= 512 && P > 64) {
+        reduce_partials_small_kernel<<<L, 256, 0, stream>>>(part, P, L, out, Cin, Cout, s_t, s_c, s_n);
+        return;
+    }
+    const ReduceJob j0{part, out, P, L, Cin, Cout, s_t, s_c, s_n};
+    const ReduceJob j1{bias_part, bias_out, P, bias_part ? Cout : 0, 1, Cout, 0, 0, 1};
+    const int nb0 = cdiv(L, 32), nb1 = bias_part ? cdiv(Cout, 32) : 0;
+    reduce_partials_kernel<<<nb0 + nb1, 256, 0, stream>>>(j0, j1, nb0);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1638,12 +1689,18 @@ static SplitK splitk_plan(int dtype, int mode, int scatter, long long M, int N, 
 static bool conv_tile_ok(int dtype, int mode, int scatter, long long DHW, int Cin, int N) {
     return dtype == DYCON_BF16 && mode == DYCON_CONV_K3 && !scatter && Cin % 32 == 0 && N % CT_BN == 0 && Cin >= 64 && DHW < 13824;
 }
+// tunables read once from the environment (diagnostic sweeps only; the defaults are what ships)
+static long long env_ll(const char* name, long long dflt) {
+    const char* v = getenv(name);
+    return v && *v ? atoll(v) : dflt;
+}
 static SplitK conv_tile_plan(long long M, int N, int Cin) {
+    static const long long target_wgs = env_ll("DYCON_TILE_SPLIT_WGS", 768);
     const int nKC = 27 * Cin / 32;
     const long long wgs = ((M + CT_BM - 1) / CT_BM) * (N / CT_BN);
     SplitK p{1, nKC};
     if (wgs >= 384) return p;
-    long long s = 768 / wgs;                                  // 3 of the 4 workgroup slots per CU: ONE round of workgroups, no tail
+    long long s = target_wgs / wgs;                           // 768: 3 of the 4 workgroup slots per CU: ONE round of workgroups, no tail
     if (s > nKC / 8) s = nKC / 8;                             // at least 8 k-steps per split
     if (s < 2) return p;
     p.kc_per_split = (int)((nKC + s - 1) / s);
@@ -1734,7 +1791,7 @@ extern "C" int dycon_conv_gemm_ex(const void* x, const void* wfrag, const float*
         (long long)Di * Hi * Wi >= 13824) {
         const int tz = cdiv(Di, CL_TZ), ty = cdiv(Hi, CL_TY), tx = cdiv(Wi, CL_TX);
         const int NT = Cout / 16;
-        const int ntb = Cout % 64 == 0 ? 4 : (Cout % 48 == 0 ? 3 : NT);
+        const int ntb = Cout % 64 == 0 ? CL_NTB64 : (Cout % 48 == 0 ? 3 : NT);
         const int nTiles = B * tz * ty * tx;
         // persistent kernels of the 16-channel level: 8 XCDs x up to 64 (p16: 2 per CU) / 128 (c1) workgroups
         if ((Cin == 16 && Cout == 16) || (Cin == 1 && (Cout == 16 || Cout == 32 || Cout == 64))) {
@@ -1882,7 +1939,8 @@ static WgradK3Plan wgrad_k3_plan(int B, int D, int H, int W, int Cin, int Cout) 
     p.gx = ((Cin + 15) / 16) * p.nCoBlk;
     const long long L = 27LL * Cin * Cout;
     long long s = 2048 / p.gx;
-    const long long cap = (24LL << 20) / (4 * L) > 0 ? (24LL << 20) / (4 * L) : 1;   // partial slabs capped at ~24 MB (fewer splits = fewer workgroups = slower: measured)
+    static const long long slab_mb = env_ll("DYCON_WGRAD_SLAB_MB", 24);
+    const long long cap = (slab_mb << 20) / (4 * L) > 0 ? (slab_mb << 20) / (4 * L) : 1;   // partial slabs capped at ~24 MB (fewer splits = fewer workgroups = slower: measured)
     if (s > cap) s = cap;
     if (s > p.nTiles) s = p.nTiles;
     if (s < 1) s = 1;
@@ -1971,12 +2029,8 @@ extern "C" int dycon_conv_wgrad(const void* x, int x_dtype, const void* gy, int 
         else DYCON_WK3(4, false);
 #undef DYCON_WK3
         DYCON_LAUNCH_CHECK();
-        launch_reduce_partials(workspace, k.splits, p.L, dw, Cin, Cout, s_t, s_c, s_n, stream);
+        launch_reduce_partials(workspace, k.splits, p.L, dw, Cin, Cout, s_t, s_c, s_n, stream, bpart, dbias);   // weights + bias: one launch
         DYCON_LAUNCH_CHECK();
-        if (dbias) {
-            launch_reduce_partials(bpart, k.splits, Cout, dbias, 1, Cout, 0, 0, 1, stream);
-            DYCON_LAUNCH_CHECK();
-        }
         return DYCON_OK;
     }
     if (x_dtype == DYCON_BF16 && g_dtype == DYCON_BF16 && wgrad_k2_ok(mode, Cin, Cout)) {
@@ -1990,12 +2044,8 @@ extern "C" int dycon_conv_wgrad(const void* x, int x_dtype, const void* gy, int 
         else DYCON_WK2(4);
 #undef DYCON_WK2
         DYCON_LAUNCH_CHECK();
-        launch_reduce_partials(workspace, k.splits, p.L, dw, Cin, Cout, s_t, s_c, s_n, stream);
+        launch_reduce_partials(workspace, k.splits, p.L, dw, Cin, Cout, s_t, s_c, s_n, stream, bpart, dbias);   // weights + bias: one launch
         DYCON_LAUNCH_CHECK();
-        if (dbias) {
-            launch_reduce_partials(bpart, k.splits, Cout, dbias, 1, Cout, 0, 0, 1, stream);
-            DYCON_LAUNCH_CHECK();
-        }
         return DYCON_OK;
     }
     if (mode == DYCON_CONV_1X1 && Cin == 16 && Cout == 2 && g_dtype == DYCON_F32) {

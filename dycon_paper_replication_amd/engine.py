@@ -21,6 +21,7 @@ from ._lib import CONV_1X1, CONV_K2S2, CONV_K3
 
 UNET_FILTERS = (16, 32, 64, 128, 256)
 VNET_NORMS = ("groupnorm", "instancenorm", "batchnorm", "none")      # VNet.py:17-24
+ABLATE = set()     # tools/ablate.py only (timing experiments with parts of the step switched off); always empty otherwise
 
 
 # --------------------------------------------------------------------------------------
@@ -174,6 +175,7 @@ class Engine:
         self.on_param_grads = None   # optional callback(name): called in backward once a layer's parameter gradients are enqueued
         self.wgrad_stream = None     # optional side stream for the weight-gradient launches of the backward (set by the trainer)
         self.feat_stream = None      # optional stream for the feature branch (projection head forward + backward), see forward()
+        self.mark = None             # optional callback(tag, stream): timeline marks (trainer._mark)
         self.Gs = {}
         self._head_range = (0, 0)
         self._wws = {}               # per-layer workspaces of the weight-gradient launches
@@ -338,7 +340,9 @@ class Engine:
 
             def bwd():
                 gy = self._take(y)
-                if self.wgrad_stream is not None:
+                if "wgrad" in ABLATE:
+                    pass
+                elif self.wgrad_stream is not None:
                     # The weight gradient only feeds the optimiser; the data gradient is the critical chain.  Enqueue the former on a
                     # second HIP stream (behind an event that marks gy ready) so the small-level wgrad / reduce launches fill the
                     # CUs the latency-bound dgrad / norm-backward kernels leave idle.  backward() joins the streams at the end.
@@ -352,6 +356,9 @@ class Engine:
                 if not need_gx:
                     return
                 cur = self._peek(x)
+                if "dgrad" in ABLATE:
+                    self._put(x, cur if cur is not None else torch.empty_like(x))
+                    return
                 if skinny:             # 1x1 head: gx[m,ci] = sum_co gy[m,co] W[co][ci]
                     wd = self._pk((name, "tcn_d"), "tcn", w, 1, Cout, Cin, Cin, 0, Cin, 0, 1)
                     gx = ops.conv_direct(gy, wd, None, CONV_1X1, Cin, x.dtype, out=cur, accumulate=cur is not None)
@@ -424,7 +431,8 @@ class Engine:
                     self._give(skip, gy)
                 dg = self.g[prefix + ".weight"] if gamma is not None else None
                 db = self.g[prefix + ".bias"] if beta is not None else None
-                gz = ops.norm_bwd(z, False, gy, stats, Nb, V, C, G, gamma, beta, relu, dg, db, chan_scale=chan_scale)
+                gz = gy if "norm_bwd" in ABLATE else ops.norm_bwd(z, False, gy, stats, Nb, V, C, G, gamma, beta, relu, dg, db,
+                                                                  chan_scale=chan_scale)
                 if self.on_param_grads is not None and gamma is not None:
                     self.on_param_grads(prefix + ".weight")
                 self._give(z, gz)
@@ -633,6 +641,12 @@ class Engine:
             else:
                 self.tape[i]()
         cs = ops.cur_stream()
+        if self.mark is not None:                             # tools/timeline.py
+            self.mark("bwd_chain_end", cs)
+            if self.feat_stream is not None:
+                self.mark("feat_bwd_end", self.feat_stream)
+            if self.wgrad_stream is not None:
+                self.mark("wgrad_end", self.wgrad_stream)
         if self.feat_stream is not None:
             fs = self.feat_stream
             ops.rec(lambda: cs.wait_stream(fs))

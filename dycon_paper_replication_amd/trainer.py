@@ -148,6 +148,7 @@ class DyconTrainer:
         # branch only at the bottleneck tensor and in the scalar loss: it runs on a third stream, beside the decoder.
         self.feat = torch.cuda.Stream(device=self.device) if cfg.overlap_features else None
         self.s_eng.feat_stream = self.feat
+        self.marks = None            # see _mark
         self._rp = None              # recorded step: dict(sig, rec, by_name, it, out, vol, lab)
         self._eager_seen = {}
         # DDP gradient buckets: contiguous arena ranges cut at parameter boundaries.  The backward writes gradients in reverse
@@ -168,6 +169,15 @@ class DyconTrainer:
             self._bucket_of = {name: (lo, hi) for name, lo, hi in self.buckets}
             self._pending = []
             self.s_eng.on_param_grads = self._on_param_grads
+
+    def _mark(self, tag, stream=None):
+        """tools/timeline.py: with `self.marks` set to a dict, record a HIP event at this point of the step on `stream` (default: the
+        launch stream); the marks are part of the recorded step, so replayed steps are timed undisturbed."""
+        if self.marks is None:
+            return
+        ev = self.marks.setdefault(tag, torch.cuda.Event(enable_timing=True))
+        st = stream if stream is not None else ops.cur_stream()
+        ops.rec(lambda: ev.record(st))
 
     def _on_param_grads(self, name):
         rng = self._bucket_of.get(name)
@@ -313,6 +323,7 @@ class DyconTrainer:
         if t_drop is None:
             t_drop = DropoutSpec("philox", seed=seed, offset=(2 * it + 1) << 42) if c.teacher_mode == "train" else DropoutSpec("off")
 
+        self._mark("step_begin")
         self.s_eng.repack()          # all weight packs of the step (student fwd + dgrad, teacher fwd): one launch each
         if not c.overlap_teacher:
             self.t_eng.repack()
@@ -323,21 +334,30 @@ class DyconTrainer:
         # small, launch-latency-bound kernels of the deep levels (6^3, 12^3: 50-100 workgroups on 256 CUs) of the two nets overlap.
         t_train = c.teacher_mode == "train"
         main = self._main = ops.cur_stream()
-        if c.overlap_teacher:
+        from .engine import ABLATE
+        if "teacher" in ABLATE:      # tools/ablate.py (timing experiment only)
+            s_logits, s_feat, _ = self.s_eng.forward(x, training=True, record=True, dropout=s_drop, update_bn=True)
+            t_logits, t_feat = s_logits, s_feat
+        elif c.overlap_teacher:
             side = self.side
             ops.rec(lambda: side.wait_stream(main))
             with ops.on_stream(self.side):
                 self.t_eng.repack()  # the teacher's packs belong to its stream (the EMA update that changed them precedes the fork)
                 t_logits, t_feat, _ = self.t_eng.forward(x_t, training=t_train, record=False, dropout=t_drop, update_bn=t_train)
+                self._mark("teacher_fwd_end")
             x_t.record_stream(self.side)
-        s_logits, s_feat, _ = self.s_eng.forward(x, training=True, record=True, dropout=s_drop, update_bn=True)   # :304
-        if c.overlap_teacher:
+        if "teacher" not in ABLATE:
+            s_logits, s_feat, _ = self.s_eng.forward(x, training=True, record=True, dropout=s_drop, update_bn=True)   # :304
+        if "teacher" in ABLATE:
+            pass
+        elif c.overlap_teacher:
             ops.rec(lambda: main.wait_stream(side))
             t_logits.record_stream(main)
             t_feat.record_stream(main)
         else:
             t_logits, t_feat, _ = self.t_eng.forward(x_t, training=t_train, record=False, dropout=t_drop, update_bn=t_train)
 
+        self._mark("student_fwd_end")
         # ---- losses (:308-357)
         world = self.world
         glob = world > 1 and c.global_batch_losses
@@ -355,6 +375,7 @@ class DyconTrainer:
             teacher_emb = t_emb if c.use_teacher_loss else None
             fargs = (s_emb, teacher_emb, mask, None, c.temp, c.gamma, bool(c.use_focal), thr)
             f_loss, fst = ops.fecl_fwd(*fargs, 1.0)
+            self._mark("fecl_fwd_end")
         if self.feat is not None:
             ops.rec(lambda: main.wait_stream(feat))       # the scalar loss (and the DDP exchange below) needs the FeCL sums
             for t in (t_feat, f_loss, fst.out, mask):
@@ -379,6 +400,7 @@ class DyconTrainer:
         # the two global-ratio terms are differentiated w.r.t. LOCAL voxels and must be SUMMED over ranks -> x world.
         ops.set_scalars(self.coef, [c.l_weight, c.l_weight * (1 - dice_kind) * gw, c.l_weight * dice_kind * gw, cw,
                                     c.u_weight, c.u_weight])
+        self._mark("loss_end")
         g_logits = ops.seg_losses_bwd(s_logits, t_logits, label, LB, beta, sums, self.coef, cons_kind)
         if self.feat is not None:
             ops.rec(lambda: feat.wait_stream(main))       # coef (and, with DDP, the all-reduced FeCL sums)
@@ -395,11 +417,13 @@ class DyconTrainer:
                     h.wait()
                 self._pending = []
             ops.rec(join)
+        self._mark("bwd_joined")
         ops.rec(lambda: self.sumsq.zero_())
         ops.sumsq(self.flat_g[: self.n_sgd], self.sumsq)
         alpha = min(1 - 1 / (it + 1), c.ema_decay)
         ops.sgd_ema(self.flat_p, self.flat_g, self.flat_m, self.flat_t, self.n_sgd, self.sumsq, c.max_grad_norm, 1.0 / world,
                     self.lr, c.momentum, c.weight_decay, alpha, self.flag)
+        self._mark("step_end")
         self.s_eng.params_changed()
         self.t_eng.params_changed()
         self.model.params_changed()

@@ -143,7 +143,7 @@ def train_step(cfg: StepConfig, st: StepState, volume, label, noise, beta: float
     return out
 
 
-def ddp_train_step(cfg: StepConfig, states, shards, beta: float, epoch: int):
+def ddp_train_step(cfg: StepConfig, states, shards, beta: float, epoch: int, student_kw: Optional[dict] = None):
     """The data-parallel iteration as the trainer runs it over W ranks, emulated in one process: every rank
     forwards its own shard [labelled | unlabelled] (so the projection head's BatchNorm sees PER-RANK batch statistics, as in the
     reference's DataParallel replicas), the Dice and FeCL-cross accumulators are summed over ranks (the 16 + 4-double
@@ -160,7 +160,7 @@ def ddp_train_step(cfg: StepConfig, states, shards, beta: float, epoch: int):
     ranks = []
     for st, (vol, lab, noise) in zip(states, shards):
         sp = {k: (v.detach().clone().requires_grad_(True) if k in names else v) for k, v in st.student.items()}
-        _, s_logits, s_feat = nets.forward(cfg.net_type, vol, sp, update_buffers=True, **kw)
+        _, s_logits, s_feat = nets.forward(cfg.net_type, vol, sp, update_buffers=True, **kw, **(student_kw or {}))
         with torch.no_grad():
             _, t_logits, t_feat = nets.forward(cfg.net_type, vol + noise, st.teacher, bn_training=cfg.teacher_bn_training,
                                                update_buffers=cfg.teacher_bn_training, **kw)
@@ -184,6 +184,7 @@ def ddp_train_step(cfg: StepConfig, states, shards, beta: float, epoch: int):
         local = cfg.l_weight * (r["ce"] + W * dice_loc) + cw * r["cons"] + cfg.u_weight * (W * r["stud"] / rows_g + W * cross_loc + r["uncl"])
         gl = torch.autograd.grad(local, [r["sp"][k] for k in names], allow_unused=True)
         gl = {k: v for k, v in zip(names, gl) if v is not None}
+        r["local_grads"] = gl
         avg = gl if avg is None else {k: avg[k] + gl[k] for k in avg}
     avg = {k: v / W for k, v in avg.items()}
     dice = 1 - (2 * g["I"] + 1e-5) / (g["Z"] + g["Y"] + 1e-5)
@@ -199,4 +200,5 @@ def ddp_train_step(cfg: StepConfig, states, shards, beta: float, epoch: int):
         ema_update(t_params, {k: st.student[k] for k in names}, cfg.ema_decay, st.iter_num)
         st.teacher.update(t_params)
         st.iter_num += 1
-    return {"loss": total, "ce": ce, "dice": dice, "cons": cons, "fecl": fecl, "uncl": uncl, "grad_norm": gnorm, "grads": avg}
+    return {"loss": total, "ce": ce, "dice": dice, "cons": cons, "fecl": fecl, "uncl": uncl, "grad_norm": gnorm, "grads": avg,
+            "local_grads": [r["local_grads"] for r in ranks]}

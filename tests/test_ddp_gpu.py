@@ -40,11 +40,14 @@ def _worker(rank, init_file, out_file, mode):
         init = dict(student_init=ON.make_vnet_params(5), teacher_init=ON.make_vnet_params(6)) if mode == "fecl" else {}
         tr = DyconTrainer(_cfg(0.5 if mode == "fecl" else 0.0), DEV, process_group=dist.group.WORLD, **init)
         assert len(tr.buckets) >= 2
-        rows = []
-        for _ in range(2):
+        rows, g0 = [], None
+        for it in range(2):
             out = tr.step(vol[idx].to(DEV), lab[idx].to(DEV), noise=noise[idx].to(DEV), s_drop=off, t_drop=off, epoch=300, beta=2.5)
-            rows.append([float(out[k]) for k in KEYS] + [float(out["grad_sumsq"].sqrt())])
-        res = {"p": tr.flat_p.cpu(), "t": tr.flat_t.cpu(), "rows": rows, "names": tr.names,
+            if it == 0 and mode == "fecl":
+                g0 = {k: (tr.g[k] / 2).cpu() for k in tr.names}     # the arena holds the SUM over the two ranks
+            # grad_sumsq is taken over the all-reduced arena, which holds the SUM over ranks (1/world is folded into the SGD kernel)
+            rows.append([float(out[k]) for k in KEYS] + [float(out["grad_sumsq"].sqrt()) / 2])
+        res = {"p": tr.flat_p.cpu(), "t": tr.flat_t.cpu(), "rows": rows, "names": tr.names, "g0": g0,
                "params": {k: tr.p[k].cpu() for k in ("block_one.conv.0.weight", "block_five.conv.3.weight", "projection.3.weight",
                                                      "projection.0.weight", "out_conv.weight")}}
     else:   # replay vs eager, bf16, on-device Philox randomness, changing batches
@@ -100,13 +103,35 @@ def test_two_rank_step_with_fecl_vs_ddp_oracle():
     got = _run("fecl")
     dbl = lambda p: {k: (v.double() if v.is_floating_point() else v) for k, v in p.items()}  # noqa: E731
     states = [OS.StepState(student=dbl(ON.make_vnet_params(5)), teacher=dbl(ON.make_vnet_params(6))) for _ in range(2)]
+    states32 = [OS.StepState(student=ON.make_vnet_params(5), teacher=ON.make_vnet_params(6)) for _ in range(2)]
     cfg = OS.StepConfig(net_type="vnet", labeled_bs=1, u_weight=0.5, base_lr=0.02)
     vol, lab, noise = make_batch(9, 4, (32, 32, 32))
-    shards = [(vol[[r, 2 + r]].double(), lab[[r, 2 + r]], noise[[r, 2 + r]].double()) for r in range(2)]
+    shards32 = [(vol[[r, 2 + r]], lab[[r, 2 + r]], noise[[r, 2 + r]]) for r in range(2)]
+    shards = [(v.double(), l, n.double()) for v, l, n in shards32]
     for step in range(2):
         ref = OS.ddp_train_step(cfg, states, shards, 2.5, 300)
-        exp = [float(ref[k]) for k in KEYS] + [float(ref["grad_norm"])]
-        np.testing.assert_allclose(got["rows"][step], exp, rtol=1e-4, atol=1e-6, err_msg=f"step {step}")
+        ref32 = OS.ddp_train_step(cfg, states32, shards32, 2.5, 300)
+        exp = np.array([float(ref[k]) for k in KEYS] + [float(ref["grad_norm"])])
+        exp32 = np.array([float(ref32[k]) for k in KEYS] + [float(ref32["grad_norm"])])
+        # loss terms: the north-star's 1e-4.  Gradient norm: 5e-4 -- ReLU decisions of voxels whose pre-activation is within fp32
+        # round-off of zero differ between any two fp32 implementations, and a flipped voxel changes its whole gradient
+        # (tools/bwd_bisect.py: ONE voxel at -2e-6 explains a 1e-2 difference of the deep-layer gradients of this very batch; the
+        # reference's own fp32 run is 1.2e-4 off its fp64 twin on this quantity in step_unet.npz).
+        got_row = np.array(got["rows"][step])
+        np.testing.assert_allclose(got_row[:6], exp[:6], rtol=1e-4, atol=1e-6, err_msg=f"step {step}")
+        assert abs(got_row[6] - exp[6]) <= max(5e-4 * exp[6], 2 * abs(exp32[6] - exp[6])), (step, got_row[6], exp[6], exp32[6])
+        if step == 0:                # the averaged gradient itself, parameter by parameter, against the double run
+            worst_h = worst_r = 0.0
+            gh = torch.cat([got["g0"][k].double().reshape(-1) for k in ref["grads"]])
+            gr = torch.cat([ref["grads"][k].reshape(-1) for k in ref["grads"]])
+            cos = float((gh * gr).sum() / (gh.norm() * gr.norm()))
+            for k, g64 in ref["grads"].items():
+                nrm = float(g64.norm()) + 1e-30
+                if nrm > 1e-6 * float(ref["grad_norm"]):      # (analytically zero gradients hold round-off only)
+                    worst_h = max(worst_h, float((got["g0"][k].double() - g64).norm()) / nrm)
+                    worst_r = max(worst_r, float((ref32["grads"][k].double() - g64).norm()) / nrm)
+            print(f"averaged gradient: cos {cos:.8f}; worst per-parameter relative L2 error: hip {worst_h:.3e}, fp32 emulation {worst_r:.3e}")
+            assert cos >= 0.9999 and worst_h <= 3e-2, (cos, worst_h)       # ReLU flips (see above): isolated voxels, direction intact
         assert exp[4] > 0.1          # FeCL really is in play
     for k, v in got["params"].items():
         np.testing.assert_allclose(v.numpy(), states[0].student[k].numpy(), rtol=1e-4, atol=2e-6, err_msg=k)
