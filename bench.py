@@ -203,6 +203,8 @@ def main():
                     "avg_launch_ms": r["ms"] / r["launches"], "launches_per_step": r["launches"] // nprof,
                     "hbm_frac": f_hbm, "mfma_frac": f_mfma,
                     "per_kernel_ms_per_step": {k: round(v["ms"] / nprof, 4) for k, v in sorted(summ.items(), key=lambda kv: -kv[1]["ms"])},
+                    "per_kernel_algorithmic_bytes_per_step": {k: v["bytes"] / nprof for k, v in summ.items()},
+                    "per_kernel_calls_per_step": {k: v["launches"] // nprof for k, v in summ.items()},
                     # every kernel family against BOTH ceilings (algorithmic bytes / flops over the summed launch durations)
                     "per_kernel_frac": {k: {"hbm": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                                             "mfma": round(v["flops"] / (v["ms"] * 1e-3) / 1e12 /

@@ -410,7 +410,7 @@ constexpr int CL_NH = CL_HZ * CL_HY * CL_HX;     // 600 halo voxels
 constexpr int CL_NV = CL_TZ * CL_TY * CL_TX;     // 256 voxels = 16 m-tiles
 
 #ifndef CL_LB2
-#define CL_LB2 1                                   // min workgroups per CU the register allocation must allow (experiments: 2)
+#define CL_LB2 2                                   // min workgroups per CU the register allocation must allow: every variant fits 2 (<32,4,2>: 248 VGPRs, no scratch)
 #endif
 #ifndef CL_NTB64
 #define CL_NTB64 4                                 // n-tiles per workgroup for 64-wide output blocks (experiments: 2)

@@ -226,6 +226,9 @@ __global__ __launch_bounds__(256) void mask_pool_kernel(const void* __restrict__
 //   different-class pairs with f_i.t_j > thr, summed over the batch / their count.
 // =================================================================================================
 constexpr int FT = 64;  // tile edge
+#ifndef FECL_P4_PREF
+#define FECL_P4_PREF 0
+#endif
 
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef short s16x4_t __attribute__((ext_vector_type(4)));
@@ -470,7 +473,7 @@ __global__ __launch_bounds__(256) void fecl_kernel(const T* __restrict__ F, cons
     // that retires it -- the global round trip no longer sits between two barriers with nothing else to do.
     constexpr int NPF = 8;                                // 64 rows x 256 bf16 = 2048 pieces / 256 threads
     // (not in the gradient pass: its 64 accumulator registers plus a staged tile leave room for one wave per SIMD only -- measured slower)
-    const bool pref = PASS != 4 && sizeof(T) == 2 && (Dm & 7) == 0 && Dp <= 256;
+    const bool pref = (PASS != 4 || FECL_P4_PREF) && sizeof(T) == 2 && (Dm & 7) == 0 && Dp <= 256;
     uint4 pfr[NPF];
     auto prefetch = [&](const T* src, int row0) {
         const unsigned short* s16 = reinterpret_cast<const unsigned short*>(src);
@@ -493,19 +496,36 @@ __global__ __launch_bounds__(256) void fecl_kernel(const T* __restrict__ F, cons
         }
     };
     const bool has_cross = (PASS == 3 || PASS == 4) && Tb;
+    // Column statistics of a tile (the slabs of the column splits combined) are requested one tile AHEAD, into registers of the first
+    // 64 threads, and written to LDS behind the barrier that retires the previous tile: their global round trip (up to 3 x CS + 2
+    // loads per column) used to sit exposed between the two barriers of every tile -- at N = 15 680 that, not the matrix cores or
+    // the pair epilogue, set the time of passes 2-4.
+    float pst[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    auto prefetch_stats = [&](int jt) {
+        if (PASS >= 2 && threadIdx.x < FT) {
+            const int gc = jt + threadIdx.x;
+            const bool vc = gc < N;
+            pst[0] = vc ? ld_max(wm, rb + gc) : 0.f;
+            pst[4] = vc ? mb[gc] : -2.f;
+            if (PASS == 4) {
+                pst[1] = vc ? ld_sum(wn, rb + gc) : 0.f;
+                pst[2] = vc ? wk[rb + gc] : 0.f;
+                pst[3] = vc ? ld_sum(wh, rb + gc) : 0.f;
+            }
+        }
+    };
     if (pref && j_beg < j_end) prefetch(Fb, j_beg);
+    if (j_beg < j_end) prefetch_stats(j_beg);
     for (int j0 = j_beg; j0 < j_end; j0 += FT) {
         __syncthreads();
         if (pref) commit(); else stage_rows(Fj, stride, Dp, Fb, j0, N, Dm);
         if (PASS >= 2 && threadIdx.x < FT) {
-            const int gc = j0 + threadIdx.x;
-            const bool vc = gc < N;
-            cst[threadIdx.x] = vc ? ld_max(wm, rb + gc) : 0.f;
-            cst[4 * FT + threadIdx.x] = vc ? mb[gc] : -2.f;
+            cst[threadIdx.x] = pst[0];
+            cst[4 * FT + threadIdx.x] = pst[4];
             if (PASS == 4) {
-                cst[FT + threadIdx.x] = vc ? ld_sum(wn, rb + gc) : 0.f;
-                cst[2 * FT + threadIdx.x] = vc ? wk[rb + gc] : 0.f;
-                cst[3 * FT + threadIdx.x] = vc ? ld_sum(wh, rb + gc) : 0.f;
+                cst[FT + threadIdx.x] = pst[1];
+                cst[2 * FT + threadIdx.x] = pst[2];
+                cst[3 * FT + threadIdx.x] = pst[3];
             }
         }
         __syncthreads();
@@ -513,6 +533,7 @@ __global__ __launch_bounds__(256) void fecl_kernel(const T* __restrict__ F, cons
             if (has_cross) prefetch(Tb, j0);
             else if (j0 + FT < j_end) prefetch(Fb, j0 + FT);
         }
+        if (j0 + FT < j_end) prefetch_stats(j0 + FT);
         f32x4 acc[4];
         gram_tile(Fi, Fj, stride, nq, wave, lane, acc);
 

@@ -342,6 +342,12 @@ class Engine:
                 gy = self._take(y)
                 if "wgrad" in ABLATE:
                     pass
+                elif "wgrad_events_only" in ABLATE and self.wgrad_stream is not None:      # the fork, without the kernels
+                    ev, cs, ws_ = torch.cuda.Event(), ops.cur_stream(), self.wgrad_stream
+                    ops.rec(lambda: (ev.record(cs), ws_.wait_event(ev)))
+                elif "wgrad_no_events" in ABLATE and self.wgrad_stream is not None:        # the kernels, without the fork (a race: timing only)
+                    with ops.on_stream(self.wgrad_stream, light=True):
+                        wgrad(gy)
                 elif self.wgrad_stream is not None:
                     # The weight gradient only feeds the optimiser; the data gradient is the critical chain.  Enqueue the former on a
                     # second HIP stream (behind an event that marks gy ready) so the small-level wgrad / reduce launches fill the

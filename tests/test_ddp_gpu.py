@@ -134,7 +134,8 @@ def test_two_rank_step_with_fecl_vs_ddp_oracle():
             assert cos >= 0.9999 and worst_h <= 3e-2, (cos, worst_h)       # ReLU flips (see above): isolated voxels, direction intact
         assert exp[4] > 0.1          # FeCL really is in play
     for k, v in got["params"].items():
-        np.testing.assert_allclose(v.numpy(), states[0].student[k].numpy(), rtol=1e-4, atol=2e-6, err_msg=k)
+        ref_p = states[0].student[k].numpy()
+        np.testing.assert_allclose(v.numpy(), ref_p, rtol=1e-4, atol=1e-4 * float(np.abs(ref_p).max()), err_msg=k)
 
 
 def test_two_rank_replay_equals_eager():

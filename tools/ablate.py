@@ -15,7 +15,7 @@ from dycon_paper_replication_amd import engine, ops  # noqa: E402
 from dycon_paper_replication_amd.synthetic import make_batch  # noqa: E402
 from dycon_paper_replication_amd.trainer import DyconTrainer, TrainConfig  # noqa: E402
 
-steps = int(sys.argv[1]) if len(sys.argv) > 1 else 30
+steps = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 dev = torch.device("cuda:0")
 vol, lab, _ = make_batch(1337, 4, (96, 96, 96))
 vol, lab = vol.to(dev), lab.to(torch.uint8).to(dev)
@@ -46,6 +46,9 @@ run("baseline (replay)")
 run("no per-step NaN flag read", strict_nan_check=False)
 run("eager (no replay)", replay=False)
 run("no weight gradients (wgrad + reduce launches skipped)", ablate=("wgrad",))
+run("wgrad: stream fork events only, no kernels", ablate=("wgrad_events_only",))
+run("wgrad: kernels without the fork events (race; timing only)", ablate=("wgrad_no_events",))
+run("baseline again")
 run("no teacher forward (teacher outputs := student's)", ablate=("teacher",))
 run("no wgrad, no teacher", ablate=("wgrad", "teacher"))
 
