@@ -21,12 +21,17 @@ static NormPlan norm_plan(long long V) {
 }
 
 // ---- stage 1: per-(n, chunk, channel) sums.  MODE 0: {sum x, sum x^2}; MODE 1: {sum g, sum g*xhat}
+// acc != NULL ("accumulator form"): instead of storing the chunk's partials for a finalize launch, every chunk adds its two sums per
+// channel to acc[n][c][2] (double atomics: the order of the <= 512 adds per address changes the last bits of a double, far below
+// the float the consumer rounds to); the consumer kernel forms the group statistics in its prologue from those C x 2 doubles.
+// One dependent launch less per normalisation, forward and backward, on the step's critical chain.
 template <typename T, int MODE>
 __global__ __launch_bounds__(256) void norm_partial_kernel(const T* __restrict__ S, const T* __restrict__ GY,
                                                            float* __restrict__ part, long long V, int C, int G,
                                                            long long rows_per_chunk, const float* __restrict__ stats,
                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                           int relu, int from_y, const float* __restrict__ chan_scale) {
+                                                           int relu, int from_y, const float* __restrict__ chan_scale,
+                                                           double* __restrict__ acc = nullptr, int nslots = 1) {
     constexpr int VN = Vec16<T>::N;
     __shared__ float sm[2][256][VN + 1];
     const int n = blockIdx.y, chunk = blockIdx.x;
@@ -90,6 +95,12 @@ __global__ __launch_bounds__(256) void norm_partial_kernel(const T* __restrict__
         const int og = o / VN, ok = o % VN;
         float s0 = 0.f, s1 = 0.f;
         for (int q = 0; q < rpi; ++q) { s0 += sm[0][q * ngrp + og][ok]; s1 += sm[1][q * ngrp + og][ok]; }
+        if (acc) {     // chunk -> one of nslots copies: <= chunks/nslots adds per address (same-address atomics serialise at the memory side)
+            double* a = acc + (((long long)n * nslots + chunk % nslots) * C + o) * 2;
+            atomicAdd(a, (double)s0);
+            atomicAdd(a + 1, (double)s1);
+            continue;
+        }
         float* d = part + ((((long long)n * gridDim.x + chunk) * C) + o) * 2;
         d[0] = s0;
         d[1] = s1;
@@ -160,17 +171,48 @@ __global__ __launch_bounds__(64) void norm_finalize_bwd_kernel(const float* __re
 }
 
 // ---- apply: y = act(x*scale[c] + shift[c]) + skip      (per sample n = blockIdx.y)
-template <typename T>
+// ACC: the statistics are not in `stats` yet -- form them from the per-channel {sum x, sum x^2} accumulators of norm_partial_kernel
+// (accumulator form) and let workgroup 0 of each sample publish them (stats_out, BatchNorm running statistics) for the backward.
+template <typename T, bool ACC>
 __global__ __launch_bounds__(256) void norm_apply_kernel(const T* __restrict__ X, T* __restrict__ Y, long long V, int C, int G,
                                                          const float* __restrict__ stats, const float* __restrict__ gamma,
                                                          const float* __restrict__ beta, int relu, const T* __restrict__ skip,
-                                                         const float* __restrict__ chan_scale) {
+                                                         const float* __restrict__ chan_scale, const double* __restrict__ acc = nullptr,
+                                                         float* __restrict__ stats_out = nullptr, float eps = 0.f,
+                                                         float* running_mean = nullptr, float* running_var = nullptr,
+                                                         float momentum = 0.f, int nslots = 1) {
     constexpr int VN = Vec16<T>::N;
     extern __shared__ float ss[];  // scale[C], shift[C], channel (dropout) scale[C]
     const int n = blockIdx.y, cpg = C / G;
     for (int c = threadIdx.x; c < C; c += 256) {
         const int g = c / cpg;
-        const float mean = stats[((long long)n * G + g) * 2], rstd = stats[((long long)n * G + g) * 2 + 1];
+        float mean, rstd;
+        if (ACC) {
+            double s0 = 0.0, s1 = 0.0;
+            for (int sl = 0; sl < nslots; ++sl)
+                for (int j = 0; j < cpg; ++j) {
+                    const double* a = acc + (((long long)n * nslots + sl) * C + g * cpg + j) * 2;
+                    s0 += a[0];
+                    s1 += a[1];
+                }
+            const double cnt = (double)V * cpg, m = s0 / cnt;
+            double var = s1 / cnt - m * m;
+            if (var < 0.0) var = 0.0;
+            mean = (float)m;
+            rstd = (float)(1.0 / sqrt(var + (double)eps));
+            if (blockIdx.x == 0 && c == g * cpg) {
+                stats_out[((long long)n * G + g) * 2] = mean;
+                stats_out[((long long)n * G + g) * 2 + 1] = rstd;
+                if (running_mean && gridDim.y == 1 && G == C) {   // nn.BatchNorm3d: unbiased variance in the running estimate
+                    running_mean[g] = (1.f - momentum) * running_mean[g] + momentum * mean;
+                    const double unb = cnt > 1.0 ? var * cnt / (cnt - 1.0) : var;
+                    running_var[g] = (1.f - momentum) * running_var[g] + momentum * (float)unb;
+                }
+            }
+        } else {
+            mean = stats[((long long)n * G + g) * 2];
+            rstd = stats[((long long)n * G + g) * 2 + 1];
+        }
         const float gm = gamma ? gamma[c] : 1.f, bt = beta ? beta[c] : 0.f;
         ss[c] = rstd * gm;
         ss[C + c] = bt - mean * rstd * gm;
@@ -198,12 +240,16 @@ __global__ __launch_bounds__(256) void norm_apply_kernel(const T* __restrict__ X
 }
 
 // ---- backward apply: gx = rstd * (gamma*g - (A + xhat*B)/cnt)
-template <typename T>
+// ACC: {A, B} per group come from the per-channel {sum g, sum g*xhat} accumulators (accumulator form of norm_partial_kernel),
+// and workgroup (0, 0) writes dgamma / dbeta (sums over the samples) -- no finalize launch.
+template <typename T, bool ACC>
 __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(const T* __restrict__ S, const T* __restrict__ GY, T* __restrict__ GX,
                                                              long long V, int C, int G, const float* __restrict__ stats,
                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
                                                              const float* __restrict__ ab, int relu, int from_y,
-                                                             const float* __restrict__ chan_scale) {
+                                                             const float* __restrict__ chan_scale,
+                                                             const double* __restrict__ acc = nullptr, float* dgamma = nullptr,
+                                                             float* dbeta = nullptr, int nslots = 1) {
     constexpr int VN = Vec16<T>::N;
     extern __shared__ float ss[];  // per channel: mean, rstd, gamma, beta, A/cnt, B/cnt, dropout scale
     const int n = blockIdx.y, cpg = C / G;
@@ -214,8 +260,28 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(const T* __restrict
         ss[C + c] = stats[((long long)n * G + g) * 2 + 1];
         ss[2 * C + c] = gamma ? gamma[c] : 1.f;
         ss[3 * C + c] = beta ? beta[c] : 0.f;
-        ss[4 * C + c] = ab[((long long)n * G + g) * 2] * inv_cnt;
-        ss[5 * C + c] = ab[((long long)n * G + g) * 2 + 1] * inv_cnt;
+        if (ACC) {
+            double a = 0.0, b = 0.0;
+            for (int sl = 0; sl < nslots; ++sl)
+                for (int j = 0; j < cpg; ++j) {
+                    const int cj = g * cpg + j;
+                    const double gm = gamma ? (double)gamma[cj] : 1.0;
+                    const double* q = acc + (((long long)n * nslots + sl) * C + cj) * 2;
+                    a += gm * q[0];
+                    b += gm * q[1];
+                }
+            ss[4 * C + c] = (float)a * inv_cnt;
+            ss[5 * C + c] = (float)b * inv_cnt;
+            if (blockIdx.x == 0 && n == 0 && (dgamma || dbeta)) {
+                double s0 = 0.0, s1 = 0.0;
+                for (int m = 0; m < (int)gridDim.y * nslots; ++m) { s0 += acc[((long long)m * C + c) * 2]; s1 += acc[((long long)m * C + c) * 2 + 1]; }
+                if (dbeta) dbeta[c] = (float)s0;
+                if (dgamma) dgamma[c] = (float)s1;
+            }
+        } else {
+            ss[4 * C + c] = ab[((long long)n * G + g) * 2] * inv_cnt;
+            ss[5 * C + c] = ab[((long long)n * G + g) * 2 + 1] * inv_cnt;
+        }
         ss[6 * C + c] = chan_scale ? chan_scale[(long long)n * C + c] : 1.f;
     }
     __syncthreads();
@@ -558,8 +624,8 @@ extern "C" int dycon_norm_apply(const void* x, void* y, int dtype, int Nb, long 
     if (int e = norm_check("norm_apply", dtype, Nb, V, C, G)) return e;
     DYCON_DISPATCH(dtype, {
         dim3 grid(apply_grid(V, C, Vec16<T>::N), Nb);
-        norm_apply_kernel<T><<<grid, 256, 3 * C * sizeof(float), stream>>>((const T*)x, (T*)y, V, C, G, stats, gamma, beta, relu,
-                                                                           (const T*)skip, chan_scale);
+        norm_apply_kernel<T, false><<<grid, 256, 3 * C * sizeof(float), stream>>>((const T*)x, (T*)y, V, C, G, stats, gamma, beta, relu,
+                                                                                  (const T*)skip, chan_scale);
     });
     DYCON_LAUNCH_CHECK();
     return DYCON_OK;
@@ -606,8 +672,67 @@ extern "C" int dycon_norm_bwd(const void* src, int from_y, const void* gy, void*
     DYCON_LAUNCH_CHECK();
     DYCON_DISPATCH(dtype, {
         dim3 grid2(apply_grid(V, C, Vec16<T>::N), Nb);
-        norm_bwd_apply_kernel<T><<<grid2, 256, 7 * C * sizeof(float), stream>>>((const T*)src, (const T*)gy, (T*)gx, V, C, G, stats,
-                                                                                gamma, beta, ab, relu, from_y, chan_scale);
+        norm_bwd_apply_kernel<T, false><<<grid2, 256, 7 * C * sizeof(float), stream>>>((const T*)src, (const T*)gy, (T*)gx, V, C, G, stats,
+                                                                                       gamma, beta, ab, relu, from_y, chan_scale);
+    });
+    DYCON_LAUNCH_CHECK();
+    return DYCON_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Accumulator forms: the caller provides `acc`, dycon_norm_acc_doubles() doubles that are ZERO on entry (a slice of an arena it
+// clears once per step; Nb x nslots x C x 2: the chunks of a sample are spread over nslots copies of its accumulators).
+// Shapes served by the one-launch kernels (dycon_norm_fwd_is_fused) ignore it; the others run statistics + apply as TWO launches
+// (no finalize): see norm_partial_kernel.  Results equal dycon_norm_fwd / dycon_norm_bwd up to the last bits of the double sums.
+// ------------------------------------------------------------------------------------------------
+static int norm_slots(long long V) {
+    const NormPlan p = norm_plan(V);
+    return p.chunks < 32 ? p.chunks : 32;
+}
+extern "C" size_t dycon_norm_acc_doubles(int Nb, long long V, int C) { return (size_t)Nb * norm_slots(V) * C * 2; }
+
+extern "C" int dycon_norm_fwd_acc(const void* x, void* y, int dtype, int Nb, long long V, int C, int G, float eps, float* stats,
+                                  const float* gamma, const float* beta, int relu, const void* skip, const float* chan_scale,
+                                  float* running_mean, float* running_var, float momentum, double* acc, dycon_stream_t stream) {
+    DYCON_REQUIRE(x && y && stats, "norm_fwd_acc: null pointer");
+    if (int e = norm_check("norm_fwd_acc", dtype, Nb, V, C, G)) return e;
+    if (norm_fused_ok(dtype, V, C, G))
+        return dycon_norm_fwd(x, y, dtype, Nb, V, C, G, eps, stats, gamma, beta, relu, skip, chan_scale, running_mean, running_var,
+                              momentum, nullptr, 0, stream);
+    DYCON_REQUIRE(acc, "norm_fwd_acc: accumulator missing");
+    const NormPlan p = norm_plan(V);
+    dim3 grid(p.chunks, Nb);
+    DYCON_DISPATCH(dtype, {
+        norm_partial_kernel<T, 0><<<grid, 256, 0, stream>>>((const T*)x, nullptr, nullptr, V, C, G, p.rows_per_chunk, nullptr, nullptr,
+                                                            nullptr, 0, 0, nullptr, acc, norm_slots(V));
+        dim3 grid2(apply_grid(V, C, Vec16<T>::N), Nb);
+        norm_apply_kernel<T, true><<<grid2, 256, 3 * C * sizeof(float), stream>>>((const T*)x, (T*)y, V, C, G, nullptr, gamma, beta, relu,
+                                                                                 (const T*)skip, chan_scale, acc, stats, eps,
+                                                                                 running_mean, running_var, momentum, norm_slots(V));
+    });
+    DYCON_LAUNCH_CHECK();
+    return DYCON_OK;
+}
+
+extern "C" int dycon_norm_bwd_acc(const void* src, const void* gy, void* gx, int dtype, int Nb, long long V, int C, int G,
+                                  const float* stats, const float* gamma, const float* beta, int relu, const float* chan_scale,
+                                  float* dgamma, float* dbeta, double* acc, float* workspace, size_t ws_bytes,
+                                  dycon_stream_t stream) {
+    DYCON_REQUIRE(src && gy && gx && stats, "norm_bwd_acc: null pointer");
+    if (int e = norm_check("norm_bwd_acc", dtype, Nb, V, C, G)) return e;
+    if (norm_fused_ok(dtype, V, C, G))
+        return dycon_norm_bwd(src, 0, gy, gx, dtype, Nb, V, C, G, stats, gamma, beta, relu, chan_scale, dgamma, dbeta, workspace,
+                              ws_bytes, stream);
+    DYCON_REQUIRE(acc, "norm_bwd_acc: accumulator missing");
+    const NormPlan p = norm_plan(V);
+    dim3 grid(p.chunks, Nb);
+    DYCON_DISPATCH(dtype, {
+        norm_partial_kernel<T, 1><<<grid, 256, 0, stream>>>((const T*)src, (const T*)gy, nullptr, V, C, G, p.rows_per_chunk, stats, gamma,
+                                                            beta, relu, 0, chan_scale, acc, norm_slots(V));
+        dim3 grid2(apply_grid(V, C, Vec16<T>::N), Nb);
+        norm_bwd_apply_kernel<T, true><<<grid2, 256, 7 * C * sizeof(float), stream>>>((const T*)src, (const T*)gy, (T*)gx, V, C, G, stats,
+                                                                                     gamma, beta, nullptr, relu, 0, chan_scale, acc,
+                                                                                     dgamma, dbeta, norm_slots(V));
     });
     DYCON_LAUNCH_CHECK();
     return DYCON_OK;

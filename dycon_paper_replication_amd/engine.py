@@ -21,6 +21,7 @@ from ._lib import CONV_1X1, CONV_K2S2, CONV_K3
 
 UNET_FILTERS = (16, 32, 64, 128, 256)
 VNET_NORMS = ("groupnorm", "instancenorm", "batchnorm", "none")      # VNet.py:17-24
+ABLATE_N = [0]
 ABLATE = set()     # tools/ablate.py only (timing experiments with parts of the step switched off); always empty otherwise
 
 
@@ -176,6 +177,16 @@ class Engine:
         self.wgrad_stream = None     # optional side stream for the weight-gradient launches of the backward (set by the trainer)
         self.feat_stream = None      # optional stream for the feature branch (projection head forward + backward), see forward()
         self.mark = None             # optional callback(tag, stream): timeline marks (trainer._mark)
+        # per-step arena of zeroed doubles for the accumulator form of the norms (ops.norm_fwd / norm_bwd `acc`): slices are handed
+        # out in call order; whoever owns the arena clears it once per step BEFORE the first norm (the trainer: one launch for both
+        # nets; a stand-alone engine: at the start of forward()).
+        # Measured SLOWER than partials -> finalize -> apply (5.8 -> 6.4 ms/step with one accumulator copy per sample: <= 512 adds
+        # per address; 6.6 ms with 32 copies: the prologue of every apply workgroup then reads 64 doubles per channel) -- DESIGN.md
+        # section 9.  Kept (tested: test_norm_accumulator_form_equals_three_launch_form), off by default.
+        self.use_acc = False
+        self.acc_arena = None
+        self.acc_external = False
+        self._acc_off = 0
         self.Gs = {}
         self._head_range = (0, 0)
         self._wws = {}               # per-layer workspaces of the weight-gradient launches
@@ -387,6 +398,16 @@ class Engine:
             self.tape.append(bwd)
         return y
 
+    ACC_DOUBLES = 1 << 20      # 8 MB: ~40 slices of Nb x 32 slots x C x 2 doubles
+
+    def _acc(self, n):
+        """n zeroed doubles of this step's arena (None when the arena is exhausted: the caller then takes the three-launch path)"""
+        if not self.use_acc or self.acc_arena is None or self._acc_off + n > self.acc_arena.numel():
+            return None
+        a = self.acc_arena[self._acc_off:self._acc_off + n]
+        self._acc_off += n
+        return a
+
     # ---------------------------------------------------------------- norm (+ReLU, +skip)
     def _norm(self, prefix, z, kind, relu=True, skip=None, training=True, chan_scale=None):
         B, C = z.shape[0], z.shape[-1]
@@ -425,8 +446,9 @@ class Engine:
             y, stats = ops.norm_fwd_slab(z, self._deferred.pop(id(z)), Nb, V, C, G, gamma, beta, relu, skip, chan_scale)
         else:
             upd = kind == "bn" and training and self.update_bn
+            acc = None if ops.norm_fwd_is_fused(z, V, C, G) else self._acc(ops.query("dycon_norm_acc_doubles", Nb, V, C))
             y, stats = ops.norm_fwd(z, Nb, V, C, G, gamma, beta, relu, skip, chan_scale, 1e-5, rm if upd else None,
-                                    rv if upd else None, 0.1)
+                                    rv if upd else None, 0.1, acc=acc)
             if upd and prefix + ".num_batches_tracked" in self.buf:
                 nbt = self.buf[prefix + ".num_batches_tracked"]
                 ops.rec(lambda: nbt.add_(1))
@@ -437,8 +459,9 @@ class Engine:
                     self._give(skip, gy)
                 dg = self.g[prefix + ".weight"] if gamma is not None else None
                 db = self.g[prefix + ".bias"] if beta is not None else None
+                acc = None if ops.norm_fwd_is_fused(z, V, C, G) else self._acc(ops.query("dycon_norm_acc_doubles", Nb, V, C))
                 gz = gy if "norm_bwd" in ABLATE else ops.norm_bwd(z, False, gy, stats, Nb, V, C, G, gamma, beta, relu, dg, db,
-                                                                  chan_scale=chan_scale)
+                                                                  chan_scale=chan_scale, acc=acc)
                 if self.on_param_grads is not None and gamma is not None:
                     self.on_param_grads(prefix + ".weight")
                 self._give(z, gz)
@@ -613,6 +636,12 @@ class Engine:
         self.dropout = dropout or DropoutSpec("off")
         self.tape, self.G = [], {}
         self._deferred = {}
+        if self.use_acc and not self.acc_external:        # stand-alone engine (module route, tests): own arena, cleared here
+            if self.acc_arena is None:
+                self.acc_arena = torch.empty(self.ACC_DOUBLES, dtype=torch.float64, device=x.device)
+            arena = self.acc_arena
+            ops.rec(lambda: arena.zero_())
+        self._acc_off = 0
         if x.dtype != self.dtype:
             x = ops.cast(x, self.dtype)
         if self.net_type == "vnet":

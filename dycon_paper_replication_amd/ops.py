@@ -315,10 +315,16 @@ def norm_stats(x, Nb, V, C, G, eps=1e-5, running_mean=None, running_var=None, mo
 
 
 def norm_fwd(x, Nb, V, C, G, gamma=None, beta=None, relu=True, skip=None, chan_scale=None, eps=1e-5, running_mean=None,
-             running_var=None, momentum=0.1):
-    """statistics + apply (one launch on the small levels).  Returns (y, stats)."""
+             running_var=None, momentum=0.1, acc=None):
+    """statistics + apply (one launch on the small levels).  Returns (y, stats).
+    acc: Nb*C*2 ZEROED doubles (a slice of the caller's per-step arena): two launches instead of three on the large levels."""
     y = torch.empty_like(x)
     stats = torch.empty(Nb * G * 2, dtype=torch.float32, device=x.device)
+    if acc is not None:
+        with _Region("norm_fwd", x.numel() * _es(x) * (4 if skip is not None else 3), 6 * x.numel()):
+            call("dycon_norm_fwd_acc", _p(x), _p(y), dt(x), Nb, V, C, G, eps, _p(stats), _p(gamma), _p(beta), int(relu), _p(skip),
+                 _p(chan_scale), _p(running_mean), _p(running_var), momentum, _p(acc), _s())
+        return y, stats
     ws = _ws(query("dycon_norm_workspace", Nb, V, C), x)
     with _Region("norm_fwd", x.numel() * _es(x) * (4 if skip is not None else 3), 6 * x.numel()):
         call("dycon_norm_fwd", _p(x), _p(y), dt(x), Nb, V, C, G, eps, _p(stats), _p(gamma), _p(beta), int(relu), _p(skip),
@@ -350,9 +356,16 @@ def norm_apply(x, stats, Nb, V, C, G, gamma=None, beta=None, relu=True, skip=Non
 
 
 def norm_bwd(src, from_y, gy, stats, Nb, V, C, G, gamma=None, beta=None, relu=True, dgamma=None, dbeta=None, out=None,
-             chan_scale=None):
+             chan_scale=None, acc=None):
     if out is None:
         out = torch.empty_like(gy)
+    if acc is not None and not from_y:
+        fused = norm_fwd_is_fused(gy, V, C, G)
+        ws = _ws(query("dycon_norm_workspace", Nb, V, C), gy) if fused else None      # (the one-launch kernels keep their workspace)
+        with _Region("norm_bwd", gy.numel() * _es(gy) * 5, 12 * gy.numel()):
+            call("dycon_norm_bwd_acc", _p(src), _p(gy), _p(out), dt(gy), Nb, V, C, G, _p(stats), _p(gamma), _p(beta), int(relu),
+                 _p(chan_scale), _p(dgamma), _p(dbeta), _p(acc), _p(ws), ws.numel() * 4 if fused else 0, _s())
+        return out
     ws = _ws(query("dycon_norm_workspace", Nb, V, C), gy)
     with _Region("norm_bwd", gy.numel() * _es(gy) * 5, 12 * gy.numel()):
         call("dycon_norm_bwd", _p(src), int(from_y), _p(gy), _p(out), dt(gy), Nb, V, C, G, _p(stats), _p(gamma), _p(beta),

@@ -69,6 +69,7 @@ class TrainConfig:
     overlap_teacher: bool = True        # teacher forward on a second HIP stream, concurrent with the student forward
     overlap_wgrad: bool = True          # weight-gradient launches of the backward on a second HIP stream (off the dgrad chain)
     overlap_features: bool = True       # feature branch (projection head, embeddings, FeCL forward + backward) on its own stream
+    norm_accumulators: bool = False     # two-launch norms through double-atomic accumulators (measured slower: DESIGN.md section 9)
     replay: bool = True                 # after two eager steps of a given input signature, record the step's launch list once and
                                         # re-issue it with patched scalars (the step is host-enqueue-bound: see DyconTrainer.step);
                                         # single-process and data-parallel runs alike
@@ -128,6 +129,14 @@ class DyconTrainer:
         self.t_buf = dict(self.ema_model.named_buffers())
         self.s_eng = Engine(cfg.model, self.p, self.g, self.s_buf, cfg.dtype, cfg.feature_scaler, cfg.normalization)
         self.t_eng = Engine(cfg.model, self.t, None, self.t_buf, cfg.dtype, cfg.feature_scaler, cfg.normalization)
+        # accumulator form of the norms (engine.use_acc; measured slower, off by default): one arena of zeroed doubles per step,
+        # shared by both nets and cleared by ONE launch at the start of the step, before the teacher stream forks
+        self.acc_arena = None
+        if cfg.norm_accumulators:
+            self.acc_arena = torch.zeros(2 * Engine.ACC_DOUBLES, dtype=torch.float64, device=self.device)
+            for eng, half in ((self.s_eng, 0), (self.t_eng, 1)):
+                eng.acc_arena = self.acc_arena[half * Engine.ACC_DOUBLES:(half + 1) * Engine.ACC_DOUBLES]
+                eng.acc_external, eng.use_acc = True, True
         self.iter_num = 0
         self.lr = cfg.base_lr * (self.world if self.world > 1 else 1)   # LR x n_gpu, train_DyCON_BraTS19.py:108-110
         self.base_lr = self.lr
@@ -324,6 +333,9 @@ class DyconTrainer:
             t_drop = DropoutSpec("philox", seed=seed, offset=(2 * it + 1) << 42) if c.teacher_mode == "train" else DropoutSpec("off")
 
         self._mark("step_begin")
+        if self.acc_arena is not None:
+            arena = self.acc_arena
+            ops.rec(lambda: arena.zero_())
         self.s_eng.repack()          # all weight packs of the step (student fwd + dgrad, teacher fwd): one launch each
         if not c.overlap_teacher:
             self.t_eng.repack()
@@ -334,7 +346,7 @@ class DyconTrainer:
         # small, launch-latency-bound kernels of the deep levels (6^3, 12^3: 50-100 workgroups on 256 CUs) of the two nets overlap.
         t_train = c.teacher_mode == "train"
         main = self._main = ops.cur_stream()
-        from .engine import ABLATE
+        from .engine import ABLATE, ABLATE_N
         if "teacher" in ABLATE:      # tools/ablate.py (timing experiment only)
             s_logits, s_feat, _ = self.s_eng.forward(x, training=True, record=True, dropout=s_drop, update_bn=True)
             t_logits, t_feat = s_logits, s_feat
@@ -357,6 +369,12 @@ class DyconTrainer:
         else:
             t_logits, t_feat, _ = self.t_eng.forward(x_t, training=t_train, record=False, dropout=t_drop, update_bn=t_train)
 
+        if "extra_launches" in ABLATE:     # tools/ablate.py: is the step bound by the dispatch rate?  N trivial launches on an idle stream
+            if not hasattr(self, "_xs"):
+                self._xs, self._xbuf = torch.cuda.Stream(device=self.device), torch.zeros(8, device=self.device)
+            with ops.on_stream(self._xs, light=True):
+                for _ in range(ABLATE_N[0]):
+                    ops.set_scalars(self._xbuf, [0.0])
         self._mark("student_fwd_end")
         # ---- losses (:308-357)
         world = self.world

@@ -149,6 +149,20 @@ int dycon_norm_bwd(const void* src, int from_y, const void* gy, void* gx, int dt
                    long long V, int C, int G, const float* stats, const float* gamma,
                    const float* beta, int relu, const float* chan_scale, float* dgamma, float* dbeta,
                    float* workspace, size_t ws_bytes, dycon_stream_t stream);
+/* Accumulator forms of dycon_norm_fwd / dycon_norm_bwd (from_y = 0): `acc` = dycon_norm_acc_doubles(Nb, V, C) doubles that are
+ * ZERO on entry (a slice of an arena the caller clears once per step).  On the shapes that are not served by the one-launch kernels, every chunk of the
+ * statistics pass adds its sums to acc (double atomics) and the apply pass forms the group statistics in its prologue: TWO launches
+ * instead of three, forward (stats written for the backward, BatchNorm running statistics updated) and backward (dgamma / dbeta
+ * written by the apply pass).  Same results up to the last bits of the double sums.  workspace: only used on the one-launch shapes. */
+size_t dycon_norm_acc_doubles(int Nb, long long V, int C);
+int dycon_norm_fwd_acc(const void* x, void* y, int dtype, int Nb, long long V, int C, int G, float eps,
+                       float* stats, const float* gamma, const float* beta, int relu, const void* skip,
+                       const float* chan_scale, float* running_mean, float* running_var, float momentum,
+                       double* acc, dycon_stream_t stream);
+int dycon_norm_bwd_acc(const void* src, const void* gy, void* gx, int dtype, int Nb, long long V, int C,
+                       int G, const float* stats, const float* gamma, const float* beta, int relu,
+                       const float* chan_scale, float* dgamma, float* dbeta, double* acc, float* workspace,
+                       size_t ws_bytes, dycon_stream_t stream);
 
 /* ---------------------------------------------------------------- data movement / pointwise
  * nn.MaxPool3d(2) (UNet3D_contrastive.py:225-237); idx holds the first-max position 0..7 */

@@ -478,3 +478,36 @@ def test_vnet_convblock_reference_fixtures(norm):
             assert float(e.g[k].abs().max()) <= 1e-4 * float(np.abs(g[pre + "g." + k[:-4] + "weight"]).max())   # analytically zero
             continue
         close(e.g[k], ref, 1e-4, 1e-4 * float(np.abs(ref).max()), k)
+
+
+@pytest.mark.parametrize("kind,C,G,V,dtype", [("gn", 16, 16, 32 * 32 * 32, torch.float32), ("gn", 32, 16, 16 * 16 * 20, torch.bfloat16),
+                                              ("in", 48, 48, 24 * 24 * 24, torch.float32), ("bn", 512, 512, 6912, torch.bfloat16),
+                                              ("gn", 64, 16, 14 * 14 * 12, torch.float32)])
+def test_norm_accumulator_form_equals_three_launch_form(kind, C, G, V, dtype):
+    """dycon_norm_fwd_acc / dycon_norm_bwd_acc (statistics by double atomics into a zeroed arena slice, group statistics formed in
+    the apply pass: two launches) against dycon_norm_fwd / dycon_norm_bwd (partials -> finalize -> apply): y, stats, gz, dgamma,
+    dbeta and the BatchNorm running statistics agree to the last bits of the double sums."""
+    gen = torch.Generator(device=DEV).manual_seed(C + V)
+    Nb = 1 if kind == "bn" else 3
+    x = (torch.randn(Nb, V, C, device=DEV, generator=gen) * 1.3 + 0.4).to(dtype)
+    gy = torch.randn(Nb, V, C, device=DEV, generator=gen).to(dtype)
+    skip = torch.randn(Nb, V, C, device=DEV, generator=gen).to(dtype)
+    gamma = (1 + 0.2 * torch.randn(C, device=DEV, generator=gen)) if kind != "in" else None
+    beta = (0.2 * torch.randn(C, device=DEV, generator=gen)) if kind != "in" else None
+    cs = (torch.rand(Nb * C, device=DEV, generator=gen) > 0.5).float() * 2
+    res = []
+    for use_acc in (False, True):
+        rm, rv = (torch.zeros(C, device=DEV), torch.ones(C, device=DEV)) if kind == "bn" else (None, None)
+        acc = torch.zeros(ops.query("dycon_norm_acc_doubles", Nb, V, C), dtype=torch.float64, device=DEV) if use_acc else None
+        y, stats = ops.norm_fwd(x, Nb, V, C, G, gamma, beta, True, skip, cs, 1e-5, rm, rv, 0.1, acc=acc)
+        dg, db = (torch.empty(C, device=DEV), torch.empty(C, device=DEV)) if gamma is not None else (None, None)
+        acc2 = torch.zeros(ops.query("dycon_norm_acc_doubles", Nb, V, C), dtype=torch.float64, device=DEV) if use_acc else None
+        gz = ops.norm_bwd(x, False, gy, stats, Nb, V, C, G, gamma, beta, True, dg, db, chan_scale=cs, acc=acc2)
+        res.append((y.float(), stats, gz.float(), dg, db, rm, rv))
+    assert not ops.norm_fwd_is_fused(x, V, C, G)
+    for a, b, name in zip(res[0], res[1], ("y", "stats", "gz", "dgamma", "dbeta", "running_mean", "running_var")):
+        if a is None:
+            continue
+        tol = 1e-6 if dtype == torch.float32 else 1e-2     # (bf16: one ulp of the stored result where a statistic's last bit differs)
+        assert float((a - b).abs().max()) <= tol * float(a.abs().max()) + 1e-9, name
+    close(res[0][1], res[1][1], 1e-6, 1e-7, "stats")
