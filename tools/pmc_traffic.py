@@ -14,7 +14,8 @@ bench_line = json.load(open(sys.argv[3])) if len(sys.argv) > 3 else None
 steps = int(sys.argv[4]) if len(sys.argv) > 4 else 3
 
 # kernel-name substring -> bench.py region (ops._Region names)
-REGIONS = [("conv_k3_p16_kernel", "conv_k3_p16"), ("conv_k3_c1_kernel", "conv_k3_c1"), ("conv_k3_lds_kernel", "conv_k3_lds"),
+REGIONS = [("head_1x1_fwd_kernel", "conv_direct"), ("head_1x1_bwd_kernel", "conv_direct"), ("grad_1x1_skinny_kernel", "conv_direct"),
+           ("conv_direct_kernel", "conv_direct"), ("conv_k3_p16_kernel", "conv_k3_p16"), ("conv_k3_c1_kernel", "conv_k3_c1"), ("conv_k3_lds_kernel", "conv_k3_lds"),
            ("conv_k3_tile_kernel", "conv_k3_tile"), ("wgrad_k3_bf16_kernel", "wgrad_k3_bf16"), ("wgrad_k2s2_bf16_kernel", "conv_wgrad"),
            ("conv_wgrad_kernel", "conv_wgrad"), ("conv_gemm_kernel", "conv_gemm"), ("norm_apply_kernel", "norm_fwd"),
            ("norm_partial_kernel<__hip_bfloat16, 0>", "norm_fwd"), ("norm_fused_fwd_kernel", "norm_fwd"),
