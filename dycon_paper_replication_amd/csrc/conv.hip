@@ -1394,6 +1394,107 @@ __global__ __launch_bounds__(256, 2) void wgrad_k2s2_bf16_kernel(const bf16* __r
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// 1x1 weight gradient on the bf16 matrix cores (the projection head, UNet3D_contrastive.py:262,265: 256 -> 512 -> 256 at 12^3):
+//   dW[ci][co] = sum_rows X[row][ci] * G[row][co].
+// Same recipe as the k=3 / k=2 kernels: 128-row tiles of X (64 input channels: 16 per wave) and G (16*NT output channels) staged in
+// natural [row][channel] order, fragments read back transposed (K = rows).  Until round 2 these two layers ran on the f32-input
+// MFMA fall-back (103 us each, the longest launches of the weight-gradient stream).
+// ------------------------------------------------------------------------------------------------
+constexpr int W1_ROWS = 128, W1_CI = 64;
+template <int NT>
+__global__ __launch_bounds__(256, 2) void wgrad_1x1_bf16_kernel(const bf16* __restrict__ X, const bf16* __restrict__ GY,
+                                                                float* __restrict__ part, float* __restrict__ bias_part, long long M,
+                                                                int Cin, int Cout, int nCoBlk, int nTiles) {
+    constexpr int CB = 16 * NT;
+    __shared__ __attribute__((aligned(16))) unsigned short Xt[W1_ROWS * W1_CI];
+    __shared__ __attribute__((aligned(16))) unsigned short Gt[W1_ROWS * CB];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int kg = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
+    const int ci0 = (blockIdx.x / nCoBlk) * W1_CI;
+    const int co0 = (blockIdx.x % nCoBlk) * CB;
+    f32x4 acc[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float bsum[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) bsum[j] = 0.f;
+    const bool do_bias = bias_part != nullptr && ci0 == 0 && wave == 0;
+    constexpr int NSX = W1_ROWS * (W1_CI / 8) / 256;                  // 4 pieces of 16 B per thread
+    constexpr int NSG = W1_ROWS * (CB / 8) / 256 > 0 ? W1_ROWS * (CB / 8) / 256 : 1;
+    uint4 sx[NSX], sg[NSG];
+    auto load_tile = [&](int tile) {
+        const long long r0 = (long long)tile * W1_ROWS;
+#pragma unroll
+        for (int it = 0; it < NSX; ++it) {
+            const int e = threadIdx.x + 256 * it;
+            const int c8 = e % (W1_CI / 8), rr = e / (W1_CI / 8);
+            sx[it] = make_uint4(0, 0, 0, 0);
+            if (r0 + rr < M) sx[it] = *reinterpret_cast<const uint4*>(X + (r0 + rr) * Cin + ci0 + 8 * c8);
+        }
+#pragma unroll
+        for (int it = 0; it < NSG; ++it) {
+            const int e = threadIdx.x + 256 * it;
+            const int c8 = e % (CB / 8), rr = e / (CB / 8);
+            sg[it] = make_uint4(0, 0, 0, 0);
+            if (e < W1_ROWS * (CB / 8) && r0 + rr < M && co0 + 8 * c8 < Cout) sg[it] = *reinterpret_cast<const uint4*>(GY + (r0 + rr) * Cout + co0 + 8 * c8);
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int it = 0; it < NSX; ++it) *reinterpret_cast<uint4*>(Xt + (threadIdx.x + 256 * it) * 8) = sx[it];
+#pragma unroll
+        for (int it = 0; it < NSG; ++it) {
+            const int e = threadIdx.x + 256 * it;
+            if (e < W1_ROWS * (CB / 8)) *reinterpret_cast<uint4*>(Gt + e * 8) = sg[it];
+        }
+    };
+    const int t_per = (nTiles + (int)gridDim.y - 1) / (int)gridDim.y;
+    const int t_beg = blockIdx.y * t_per, t_end = min(nTiles, t_beg + t_per);
+    if (t_beg < t_end) load_tile(t_beg);
+    for (int tile = t_beg; tile < t_end; ++tile) {
+        __syncthreads();
+        store_tile();
+        __syncthreads();
+        if (tile + 1 < t_end) load_tile(tile + 1);
+#pragma unroll
+        for (int s_ = 0; s_ < W1_ROWS / 32; ++s_) {
+            const int v = 32 * s_ + 8 * kg + q;                         // this lane's row of the k-step (and v + 4)
+            const unsigned short* a0 = Xt + v * W1_CI + 16 * wave + 4 * p;
+            const bf16x8 afr = tr_frag(a0, a0 + 4 * W1_CI);
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const unsigned short* g0 = Gt + v * CB + 16 * j + 4 * p;
+                const bf16x8 bfr = tr_frag(g0, g0 + 4 * CB);
+                if (do_bias) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) bsum[j] += (float)bfr[e];
+                }
+                acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr, bfr, acc[j], 0, 0, 0);
+            }
+        }
+    }
+    const int col = lane & 15;
+    float* dst = part + (long long)blockIdx.y * Cin * Cout;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int co = co0 + 16 * j + col;
+        if (co >= Cout) continue;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dst[((long long)ci0 + 16 * wave + 4 * kg + i) * Cout + co] = acc[j][i];
+    }
+    if (do_bias) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            float v = bsum[j];
+            v += __shfl_xor(v, 16, 64);
+            v += __shfl_xor(v, 32, 64);
+            const int co = co0 + 16 * j + col;
+            if (kg == 0 && co < Cout) bias_part[(long long)blockIdx.y * Cout + co] = v;
+        }
+    }
+}
+
 // skinny weight gradient: thread j owns output element (t, ci, co); the block walks a voxel slice
 template <typename TX, typename TG, int MODE>
 __global__ __launch_bounds__(256) void conv_wgrad_direct_kernel(const TX* __restrict__ X, const TG* __restrict__ GY,
@@ -1524,30 +1625,45 @@ __global__ __launch_bounds__(256) void head_1x1_bwd_kernel(const float* __restri
 // One launch serves up to two jobs (the weight slabs and the bias-gradient partials of the same wgrad call): blocks
 // [0, nb0) belong to job 0, the rest to job 1.
 struct ReduceJob { const float* part; float* out; int P, L, Cin, Cout; long long s_t, s_c, s_n; };
+// VEC = 4: a thread owns 4 consecutive outputs (one 16-byte load per partial row: the slabs are the bulk of a weight-gradient call's
+// HBM traffic, ~25 MB per call); 256 threads = 32 output quads x 8 partial lanes.  VEC = 1: any L.
+template <int VEC>
 __global__ __launch_bounds__(256) void reduce_partials_kernel(ReduceJob j0, ReduceJob j1, int nb0) {
-    __shared__ float sm[8][33];
+    __shared__ float sm[8][32 * VEC + 1];
     const bool second = (int)blockIdx.x >= nb0;
     const ReduceJob& jb = second ? j1 : j0;
     const int bid = second ? blockIdx.x - nb0 : blockIdx.x;
     const int o = threadIdx.x & 31, pl = threadIdx.x >> 5;
-    const int i = bid * 32 + o;
+    const int i = (bid * 32 + o) * VEC;
     const int L = jb.L, P = jb.P;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;          // four independent chains: the loads of a thread are 8*L floats apart
-    if (i < L) {
-        const float* pp = jb.part + i;
-        int p = pl;
-        for (; p + 24 < P; p += 32) {
-            s0 += pp[(long long)p * L]; s1 += pp[(long long)(p + 8) * L]; s2 += pp[(long long)(p + 16) * L]; s3 += pp[(long long)(p + 24) * L];
+    float s[4][VEC];                                       // four independent chains: the loads of a thread are 8*L floats apart
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) s[c][v] = 0.f;
+    auto add = [&](int c, long long p) {
+        if (VEC == 4) {
+            const float4 q = *reinterpret_cast<const float4*>(jb.part + p * L + i);
+            s[c][0] += q.x; s[c][1 % VEC] += q.y; s[c][2 % VEC] += q.z; s[c][3 % VEC] += q.w;
+        } else {
+            s[c][0] += jb.part[p * L + i];
         }
-        for (; p < P; p += 8) s0 += pp[(long long)p * L];
+    };
+    if (i < L) {
+        int p = pl;
+        for (; p + 24 < P; p += 32) { add(0, p); add(1, p + 8); add(2, p + 16); add(3, p + 24); }
+        for (; p < P; p += 8) add(0, p);
     }
-    sm[pl][o] = (s0 + s1) + (s2 + s3);
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) sm[pl][o * VEC + v] = (s[0][v] + s[1][v]) + (s[2][v] + s[3][v]);
     __syncthreads();
-    if (pl == 0 && i < L) {
+    for (int e = threadIdx.x; e < 32 * VEC; e += 256) {
+        const int ii = bid * 32 * VEC + e;
+        if (ii >= L) continue;
         float tot = 0.f;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) tot += sm[k][o];
-        const int co = i % jb.Cout, ci = (i / jb.Cout) % jb.Cin, t = i / (jb.Cout * jb.Cin);
+        for (int k = 0; k < 8; ++k) tot += sm[k][e];
+        const int co = ii % jb.Cout, ci = (ii / jb.Cout) % jb.Cin, t = ii / (jb.Cout * jb.Cin);
         jb.out[t * jb.s_t + ci * jb.s_c + co * jb.s_n] = tot;
     }
 }
@@ -1563,8 +1679,13 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ X, fl
     const long long r1 = min(rows, r0 + rows_per_block);
     if (C <= 8 && 256 % C == 0) {          // skinny widths (2-class logits): threads tile [rows][C], LDS tree over rows
         const int c = threadIdx.x % C, rr = threadIdx.x / C, rpi2 = 256 / C;
-        float s = 0.f;
-        for (long long r = r0 + rr; r < r1; r += rpi2) s += ldf(X + r * C + c);
+        float s = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;     // four loads in flight per thread (a single dependent chain was latency-bound)
+        long long r = r0 + rr;
+        for (; r + 3 * rpi2 < r1; r += 4 * rpi2) {
+            s += ldf(X + r * C + c); s1 += ldf(X + (r + rpi2) * C + c); s2 += ldf(X + (r + 2 * rpi2) * C + c); s3 += ldf(X + (r + 3 * rpi2) * C + c);
+        }
+        for (; r < r1; r += rpi2) s += ldf(X + r * C + c);
+        s = (s + s1) + (s2 + s3);
         sm[threadIdx.x][0] = s;
         __syncthreads();
         if (threadIdx.x < C) {
@@ -1626,8 +1747,14 @@ static void launch_reduce_partials(const float* part, int P, int L, float* out, 
     }
     const ReduceJob j0{part, out, P, L, Cin, Cout, s_t, s_c, s_n};
     const ReduceJob j1{bias_part, bias_out, P, bias_part ? Cout : 0, 1, Cout, 0, 0, 1};
-    const int nb0 = cdiv(L, 32), nb1 = bias_part ? cdiv(Cout, 32) : 0;
-    reduce_partials_kernel<<<nb0 + nb1, 256, 0, stream>>>(j0, j1, nb0);
+    const bool vec = L % 4 == 0 && (!bias_part || Cout % 4 == 0) && ((uintptr_t)part & 15) == 0 && (!bias_part || ((uintptr_t)bias_part & 15) == 0);
+    if (vec) {
+        const int nb0 = cdiv(L, 128), nb1 = bias_part ? cdiv(Cout, 128) : 0;
+        reduce_partials_kernel<4><<<nb0 + nb1, 256, 0, stream>>>(j0, j1, nb0);
+    } else {
+        const int nb0 = cdiv(L, 32), nb1 = bias_part ? cdiv(Cout, 32) : 0;
+        reduce_partials_kernel<1><<<nb0 + nb1, 256, 0, stream>>>(j0, j1, nb0);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1966,6 +2093,21 @@ static WgradK3Plan wgrad_k2_plan(int B, int Di, int Hi, int Wi, int Cin, int Cou
     p.splits = (int)s;
     return p;
 }
+static bool wgrad_1x1_ok(int mode, int Cin, int Cout) {
+    return mode == DYCON_CONV_1X1 && Cin % W1_CI == 0 && Cout % 16 == 0 && (Cout == 16 || Cout == 32 || Cout % 64 == 0);
+}
+static WgradK3Plan wgrad_1x1_plan(long long M, int Cin, int Cout) {
+    WgradK3Plan p{};
+    p.nTiles = (int)((M + W1_ROWS - 1) / W1_ROWS);
+    p.NT = Cout >= 64 ? 4 : Cout / 16;
+    p.nCoBlk = cdiv(Cout, 16 * p.NT);
+    p.gx = (Cin / W1_CI) * p.nCoBlk;
+    long long s_ = 512 / p.gx;
+    if (s_ > p.nTiles) s_ = p.nTiles;
+    if (s_ < 1) s_ = 1;
+    p.splits = (int)s_;
+    return p;
+}
 static bool wgrad_k3_ok(int mode, int Cin, int Cout) {
     return mode == DYCON_CONV_K3 && (Cin % 16 == 0 || Cin == 1) && Cout % 16 == 0 && (Cout == 16 || Cout == 32 || Cout % 64 == 0);
 }
@@ -1980,6 +2122,11 @@ extern "C" size_t dycon_conv_wgrad_workspace(int mode, int B, int Di, int Hi, in
     }
     int Do, Ho, Wo;
     row_grid(mode, Di, Hi, Wi, Do, Ho, Wo);
+    if (wgrad_1x1_ok(mode, Cin, Cout)) {
+        const WgradK3Plan k = wgrad_1x1_plan((long long)B * Di * Hi * Wi, Cin, Cout);
+        const size_t n2 = ((size_t)k.splits * p.L + (size_t)k.splits * Cout) * sizeof(float);
+        if (n2 > need) need = n2;
+    }
     return need + dycon_colsum_workspace((long long)B * Do * Ho * Wo, Cout) + 64;   // room for the un-fused bias gradient
 }
 
@@ -2045,6 +2192,22 @@ extern "C" int dycon_conv_wgrad(const void* x, int x_dtype, const void* gy, int 
 #undef DYCON_WK2
         DYCON_LAUNCH_CHECK();
         launch_reduce_partials(workspace, k.splits, p.L, dw, Cin, Cout, s_t, s_c, s_n, stream, bpart, dbias);   // weights + bias: one launch
+        DYCON_LAUNCH_CHECK();
+        return DYCON_OK;
+    }
+    if (x_dtype == DYCON_BF16 && g_dtype == DYCON_BF16 && wgrad_1x1_ok(mode, Cin, Cout)) {
+        const long long M = (long long)B * Di * Hi * Wi;
+        const WgradK3Plan k = wgrad_1x1_plan(M, Cin, Cout);
+        float* bpart = dbias ? workspace + (size_t)k.splits * p.L : nullptr;
+        dim3 grid(k.gx, k.splits);
+#define DYCON_W11(NTV) \
+    wgrad_1x1_bf16_kernel<NTV><<<grid, 256, 0, stream>>>((const bf16*)x, (const bf16*)gy, workspace, bpart, M, Cin, Cout, k.nCoBlk, k.nTiles)
+        if (k.NT == 1) DYCON_W11(1);
+        else if (k.NT == 2) DYCON_W11(2);
+        else DYCON_W11(4);
+#undef DYCON_W11
+        DYCON_LAUNCH_CHECK();
+        launch_reduce_partials(workspace, k.splits, p.L, dw, Cin, Cout, s_t, s_c, s_n, stream, bpart, dbias);
         DYCON_LAUNCH_CHECK();
         return DYCON_OK;
     }

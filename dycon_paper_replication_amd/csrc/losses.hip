@@ -741,7 +741,10 @@ extern "C" int dycon_seg_losses_fwd(const float* s_logits, const float* t_logits
     DYCON_REQUIRE(LB == 0 || labels, "seg_losses_fwd: labels missing");
     DYCON_REQUIRE(label_bytes == 1 || label_bytes == 8, "seg_losses_fwd: labels must be uint8 or int64");
     if (hipMemsetAsync(sums, 0, 16 * sizeof(double), stream) != hipSuccess) { dycon_set_error("seg_losses_fwd: memset failed"); return DYCON_ERR_LAUNCH; }
-    seg_losses_fwd_kernel<<<lgrid((long long)B * V), 256, 0, stream>>>((const float2*)s_logits, (const float2*)t_logits, labels,
+    // 512 workgroups (two per CU): every workgroup ends with 11 double atomics onto the same 11 addresses, and same-address
+    // atomics serialise at the memory side -- with 2048 workgroups that tail was most of the kernel (77 us for 60 MB)
+    const long long wg = ((long long)B * V + 255) / 256;
+    seg_losses_fwd_kernel<<<(int)(wg < 512 ? (wg < 1 ? 1 : wg) : 512), 256, 0, stream>>>((const float2*)s_logits, (const float2*)t_logits, labels,
                                                                        label_bytes, B, LB, V, beta, sums);
     DYCON_LAUNCH_CHECK();
     return DYCON_OK;

@@ -65,6 +65,8 @@ FULL_CASES = [
     ("k2s2", 32, 64, (48, 48, 48)),
     ("deconv", 32, 16, (48, 48, 48)),
     ("deconv", 64, 32, (24, 24, 24)),
+    ("1x1", 256, 512, (12, 12, 12)),  # projection head (bf16 MFMA 1x1 weight gradient, 54 row tiles over 16 splits)
+    ("1x1", 512, 256, (12, 12, 12)),
 ]
 
 
@@ -72,7 +74,7 @@ FULL_CASES = [
 def test_conv_full_size_bf16(kind, cin, cout, sp):
     rng = np.random.default_rng(zlib.crc32(repr((kind, cin, cout, sp)).encode()))
     B = 4
-    k = {"k3": 3, "k2s2": 2, "deconv": 2}[kind]
+    k = {"k3": 3, "k2s2": 2, "deconv": 2, "1x1": 1}[kind]
     wshape = (cin, cout, k, k, k) if kind == "deconv" else (cout, cin, k, k, k)
     w = T((rng.standard_normal(wshape) / np.sqrt(cin * k ** 3)).astype(np.float32))
     b = T(rng.standard_normal(cout).astype(np.float32))
@@ -87,6 +89,8 @@ def test_conv_full_size_bf16(kind, cin, cout, sp):
         yr = F.conv3d(xr, wq, br, padding=1)
     elif kind == "k2s2":
         yr = F.conv3d(xr, wq, br, stride=2)
+    elif kind == "1x1":
+        yr = F.conv3d(xr, wq, br)
     else:
         yr = F.conv_transpose3d(xr, wq, br, stride=2)
     gy = torch.randn(tuple(yr.shape), generator=torch.Generator().manual_seed(7)).bfloat16().float()
