@@ -93,38 +93,57 @@ __global__ void pack_tcn_kernel(const float* __restrict__ w, float* __restrict__
     }
 }
 
-// all weight packs of a step in ONE launch: jobs[] lives in device memory (built once; pointers are stable arena views)
+// all weight packs of a step in ONE launch: jobs[] lives in device memory (built once; pointers are stable arena views).
+// One thread per FRAGMENT PIECE (the G = 8 / 4 consecutive k of one lane): the (k-chunk, n-tile, lane) decode and the column's
+// source offset are computed once per piece and (tap, channel) advance incrementally -- with one thread per element the kernel was
+// bound by ~10 integer divisions per value (52 us for 57 MB at the head of every step's dependent chain).
 __global__ __launch_bounds__(256) void pack_batch_kernel(const dycon_pack_job_t* __restrict__ jobs) {
     const dycon_pack_job_t jb = jobs[blockIdx.y];
-    const int G = jb.kind == 0 ? 8 : 4, KC = jb.kind == 0 ? 32 : 16;
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < jb.total; i += (long long)gridDim.x * 256) {
-        float v = 0.f;
-        if (jb.kind == 2) {          // plain fp32 [T][Cin][N]
+    if (jb.kind == 2) {          // plain fp32 [T][Cin][N]
+        for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < jb.total; i += (long long)gridDim.x * 256) {
             const int n = (int)(i % jb.N);
             const long long q = i / jb.N;
             const int c = (int)(q % jb.Cin);
             int t = (int)(q / jb.Cin);
             if (jb.flip) t = jb.T - 1 - t;
-            v = jb.w[t * jb.s_t + c * jb.s_c + (long long)(n / jb.N0) * jb.s_n1 + (long long)(n % jb.N0) * jb.s_n0];
-            ((float*)jb.out)[i] = v;
-            continue;
+            ((float*)jb.out)[i] = jb.w[t * jb.s_t + c * jb.s_c + (long long)(n / jb.N0) * jb.s_n1 + (long long)(n % jb.N0) * jb.s_n0];
         }
-        const int e = (int)(i % G);
-        long long q = i / G;
-        const int lane = (int)(q % 64);
-        q /= 64;
+        return;
+    }
+    const int G = jb.kind == 0 ? 8 : 4, KC = jb.kind == 0 ? 32 : 16;
+    const long long pieces = jb.total / G;
+    const int K = jb.T * jb.Cin;
+    for (long long pi = (long long)blockIdx.x * 256 + threadIdx.x; pi < pieces; pi += (long long)gridDim.x * 256) {
+        const int lane = (int)(pi & 63);
+        const long long q = pi >> 6;
         const int nt = (int)(q % jb.NT);
         const int kc = (int)(q / jb.NT);
-        const int k = kc * KC + G * (lane >> 4) + e;
         const int n = nt * 16 + (lane & 15);
-        if (k < jb.T * jb.Cin && n < jb.N) {
-            int t = k / jb.Cin;
-            const int c = k - t * jb.Cin;
-            if (jb.flip) t = jb.T - 1 - t;
-            v = jb.w[t * jb.s_t + c * jb.s_c + (long long)(n / jb.N0) * jb.s_n1 + (long long)(n % jb.N0) * jb.s_n0];
+        int k = kc * KC + G * (lane >> 4);
+        int t = k / jb.Cin, c = k - t * jb.Cin;
+        const bool ncol = n < jb.N;
+        const long long noff = ncol ? (long long)(n / jb.N0) * jb.s_n1 + (long long)(n % jb.N0) * jb.s_n0 : 0;
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            v[e] = 0.f;
+            if (e < G && ncol && k < K) {
+                const int tt = jb.flip ? jb.T - 1 - t : t;
+                v[e] = jb.w[tt * jb.s_t + c * jb.s_c + noff];
+            }
+            ++k;
+            if (++c == jb.Cin) { c = 0; ++t; }
         }
-        if (jb.kind == 0) ((bf16*)jb.out)[i] = __float2bfloat16(v);
-        else ((float*)jb.out)[i] = v;
+        if (jb.kind == 0) {
+            uint4 o;
+            o.x = (unsigned)f32_to_bf16_bits(v[0]) | ((unsigned)f32_to_bf16_bits(v[1]) << 16);
+            o.y = (unsigned)f32_to_bf16_bits(v[2]) | ((unsigned)f32_to_bf16_bits(v[3]) << 16);
+            o.z = (unsigned)f32_to_bf16_bits(v[4]) | ((unsigned)f32_to_bf16_bits(v[5]) << 16);
+            o.w = (unsigned)f32_to_bf16_bits(v[6]) | ((unsigned)f32_to_bf16_bits(v[7]) << 16);
+            reinterpret_cast<uint4*>(jb.out)[pi] = o;
+        } else {
+            reinterpret_cast<float4*>(jb.out)[pi] = make_float4(v[0], v[1], v[2], v[3]);
+        }
     }
 }
 
@@ -138,7 +157,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const T* __restrict__ X,
                                                         const float* __restrict__ bias, T* __restrict__ Y, int B, int Di,
                                                         int Hi, int Wi, int Cin, int Do, int Ho, int Wo, int N, int Cout,
                                                         int NT, int nKC, int accumulate, float* __restrict__ slab,
-                                                        int kc_per_split) {
+                                                        int kc_per_split, int span_major = 0) {
     constexpr int G = Frag<T>::G, KC = Frag<T>::KC;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 15, kg = lane >> 4;
@@ -208,7 +227,9 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const T* __restrict__ X,
 #pragma unroll
             for (int j = 0; j < NTB; ++j) {
                 const int n = (nt0 + j) * 16 + r;
-                if (nt0 + j < NT && n < N) sl[mo * N + n] = acc[j][i];
+                // span_major (finish deferred to the one-launch norm): [8-channel span][row][8] -- that norm's workgroups own 8-16
+                // channels of one sample and then read their share of every slab as ONE contiguous run
+                if (nt0 + j < NT && n < N) sl[span_major ? ((long long)(n >> 3) * M + mo) * 8 + (n & 7) : mo * N + n] = acc[j][i];
             }
         }
         return;
@@ -272,7 +293,7 @@ constexpr int CT_BM = 64, CT_BN = 128, CT_AS = 40;          // A rows padded to 
 __global__ __launch_bounds__(256, 4) void conv_k3_tile_kernel(const bf16* __restrict__ X, const bf16* __restrict__ Wf,
                                                            const float* __restrict__ bias, bf16* __restrict__ Y,
                                                            float* __restrict__ slab, int B, int D, int H, int W, int Cin, int N,
-                                                           int NT, int nKC, int kc_per_split, int accumulate) {
+                                                           int NT, int nKC, int kc_per_split, int accumulate, int span_major = 0) {
     __shared__ __attribute__((aligned(16))) unsigned short As[2][CT_BM * CT_AS];
     __shared__ __attribute__((aligned(16))) unsigned short Bs[2][8 * 64 * 8];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -370,7 +391,7 @@ __global__ __launch_bounds__(256, 4) void conv_k3_tile_kernel(const bf16* __rest
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int n = (nt0 + wn * 4 + j) * 16 + r;
-                    if (n < N) sl[mo * N + n] = acc[m][j][i];
+                    if (n < N) sl[span_major ? ((long long)(n >> 3) * M + mo) * 8 + (n & 7) : mo * N + n] = acc[m][j][i];
                 }
             }
         return;
@@ -971,14 +992,37 @@ __global__ __launch_bounds__(256) void conv_k3_c1_kernel(const bf16* __restrict_
 }
 
 // y[m, n] (+)= bias[n] + sum_z slab[z][m][n]   (ordered: deterministic)
+// Four consecutive outputs per thread (N % 16 == 0, so a quad never straddles a row): one 16-byte load per slab, the slabs of a
+// thread all in flight.  This launch follows every split-K convolution on the step's dependent chain.
 template <typename T>
 __global__ __launch_bounds__(256) void splitk_finish_kernel(const float* __restrict__ slab, int splits, long long MN, int N,
                                                             const float* __restrict__ bias, T* __restrict__ Y, int accumulate) {
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < MN; i += (long long)gridDim.x * 256) {
-        float v = bias ? bias[i % N] : 0.f;
-        for (int z = 0; z < splits; ++z) v += slab[(long long)z * MN + i];
-        if (accumulate) v += ldf(Y + i);
-        stf(Y + i, v);
+    const long long nq = MN >> 2;
+    for (long long q = (long long)blockIdx.x * 256 + threadIdx.x; q < nq; q += (long long)gridDim.x * 256) {
+        const long long i = q << 2;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (bias) v = *reinterpret_cast<const float4*>(bias + i % N);
+        for (int z = 0; z < splits; ++z) {        // (ordered: the same summation order as before, per element)
+            const float4 p = *reinterpret_cast<const float4*>(slab + (long long)z * MN + i);
+            v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
+        }
+        if constexpr (sizeof(T) == 2) {
+            if (accumulate) {
+                const uint2 o = *reinterpret_cast<const uint2*>(Y + i);
+                v.x += bf16_bits_to_f32((unsigned short)(o.x & 0xffffu)); v.y += bf16_bits_to_f32((unsigned short)(o.x >> 16));
+                v.z += bf16_bits_to_f32((unsigned short)(o.y & 0xffffu)); v.w += bf16_bits_to_f32((unsigned short)(o.y >> 16));
+            }
+            uint2 o;
+            o.x = (unsigned)f32_to_bf16_bits(v.x) | ((unsigned)f32_to_bf16_bits(v.y) << 16);
+            o.y = (unsigned)f32_to_bf16_bits(v.z) | ((unsigned)f32_to_bf16_bits(v.w) << 16);
+            *reinterpret_cast<uint2*>(Y + i) = o;
+        } else {
+            if (accumulate) {
+                const float4 o = *reinterpret_cast<const float4*>(Y + i);
+                v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+            }
+            *reinterpret_cast<float4*>(Y + i) = v;
+        }
     }
 }
 
@@ -1822,12 +1866,12 @@ static long long env_ll(const char* name, long long dflt) {
     return v && *v ? atoll(v) : dflt;
 }
 static SplitK conv_tile_plan(long long M, int N, int Cin) {
-    static const long long target_wgs = env_ll("DYCON_TILE_SPLIT_WGS", 768);
+    static const long long target_wgs = env_ll("DYCON_TILE_SPLIT_WGS", 512);
     const int nKC = 27 * Cin / 32;
     const long long wgs = ((M + CT_BM - 1) / CT_BM) * (N / CT_BN);
     SplitK p{1, nKC};
     if (wgs >= 384) return p;
-    long long s = target_wgs / wgs;                           // 768: 3 of the 4 workgroup slots per CU: ONE round of workgroups, no tail
+    long long s = target_wgs / wgs;                           // 512 workgroups (2 of the 4 slots per CU, one round): 5.66-5.68 ms/step against 5.74 at 768 and 5.72 at 256
     if (s > nKC / 8) s = nKC / 8;                             // at least 8 k-steps per split
     if (s < 2) return p;
     p.kc_per_split = (int)((nKC + s - 1) / s);
@@ -1856,9 +1900,9 @@ static void launch_gemm(const void* x, const void* wf, const float* bias, void* 
     dim3 grid(cdiv(M, 64), cdiv(NT, NTB), split ? sk.splits : 1);
     conv_gemm_kernel<T, MODE, SC><<<grid, 256, 0, stream>>>((const T*)x, (const T*)wf, bias, (T*)y, B, Di, Hi, Wi, Cin, Do, Ho,
                                                             Wo, N, Cout, NT, nKC, accumulate, split ? workspace : nullptr,
-                                                            sk.kc_per_split);
+                                                            sk.kc_per_split, split && defer_finish && N % 8 == 0);
     if (split && !defer_finish) {
-        long long blocks = (M * N + 255) / 256;
+        long long blocks = (M * N / 4 + 255) / 256;
         if (blocks > 2048) blocks = 2048;
         splitk_finish_kernel<T><<<(int)blocks, 256, 0, stream>>>(workspace, sk.splits, M * N, N, bias, (T*)y, accumulate);
     }
@@ -1952,10 +1996,10 @@ extern "C" int dycon_conv_gemm_ex(const void* x, const void* wfrag, const float*
         const bool split = sk.splits > 1 && workspace && ws_bytes >= (size_t)sk.splits * M * N * sizeof(float);
         dim3 grid(cdiv(M, CT_BM), N / CT_BN, split ? sk.splits : 1);
         conv_k3_tile_kernel<<<grid, 256, 0, stream>>>((const bf16*)x, (const bf16*)wfrag, bias, (bf16*)y, split ? workspace : nullptr, B,
-                                                      Di, Hi, Wi, Cin, N, NT, nKC, sk.kc_per_split, accumulate);
+                                                      Di, Hi, Wi, Cin, N, NT, nKC, sk.kc_per_split, accumulate, split && defer_finish);
         DYCON_LAUNCH_CHECK();
         if (split && !defer_finish) {
-            long long blocks = (M * N + 255) / 256;
+            long long blocks = (M * N / 4 + 255) / 256;
             if (blocks > 2048) blocks = 2048;
             splitk_finish_kernel<bf16><<<(int)blocks, 256, 0, stream>>>(workspace, sk.splits, M * N, N, bias, (bf16*)y, accumulate);
             DYCON_LAUNCH_CHECK();

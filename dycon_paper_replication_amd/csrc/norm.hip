@@ -107,23 +107,35 @@ __global__ __launch_bounds__(256) void norm_partial_kernel(const T* __restrict__
     }
 }
 
-// ---- stage 2 (forward): mean / rstd per (n, g) (+ BatchNorm running statistics).  One wave per (n, g).
-__global__ __launch_bounds__(64) void norm_finalize_stats_kernel(const float* __restrict__ part, int Nb, int chunks, int C, int G,
-                                                                 long long V, float eps, float* __restrict__ stats,
-                                                                 float* running_mean, float* running_var, float momentum) {
-    const int i = blockIdx.x, lane = threadIdx.x;
+// two doubles summed over the 256 threads of a workgroup (result valid in thread 0)
+__device__ __forceinline__ void block_sum2_double(double& s0, double& s1) {
+    __shared__ double red[2][4];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { s0 += __shfl_xor(s0, o, 64); s1 += __shfl_xor(s1, o, 64); }
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) { red[0][w] = s0; red[1][w] = s1; }
+    __syncthreads();
+    s0 = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+    s1 = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+}
+
+// ---- stage 2 (forward): mean / rstd per (n, g) (+ BatchNorm running statistics).  One 256-thread workgroup per (n, g): the <= 512 x cpg
+// partials are two loads per thread, all in flight at once (this launch sits on the step's dependent chain 38 times).
+__global__ __launch_bounds__(256) void norm_finalize_stats_kernel(const float* __restrict__ part, int Nb, int chunks, int C, int G,
+                                                                  long long V, float eps, float* __restrict__ stats,
+                                                                  float* running_mean, float* running_var, float momentum) {
+    const int i = blockIdx.x;
     const int n = i / G, g = i % G, cpg = C / G;
     double s0 = 0.0, s1 = 0.0;
     const int items = chunks * cpg;
-    for (int e = lane; e < items; e += 64) {
+    for (int e = threadIdx.x; e < items; e += 256) {
         const int ch = e / cpg, c = g * cpg + e % cpg;
         const float* p = part + ((((long long)n * chunks + ch) * C) + c) * 2;
         s0 += p[0];
         s1 += p[1];
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { s0 += __shfl_xor(s0, o, 64); s1 += __shfl_xor(s1, o, 64); }
-    if (lane != 0) return;
+    block_sum2_double(s0, s1);
+    if (threadIdx.x != 0) return;
     const double cnt = (double)V * cpg;
     const double mean = s0 / cnt;
     double var = s1 / cnt - mean * mean;
@@ -138,35 +150,33 @@ __global__ __launch_bounds__(64) void norm_finalize_stats_kernel(const float* __
 }
 
 // ---- stage 2 (backward): blocks [0, Nb*G): per-(n,g) {A, B}; blocks [Nb*G, Nb*G + C): per-channel dgamma/dbeta
-__global__ __launch_bounds__(64) void norm_finalize_bwd_kernel(const float* __restrict__ part, int Nb, int chunks, int C, int G,
-                                                               const float* __restrict__ gamma, float* __restrict__ ab,
-                                                               float* dgamma, float* dbeta) {
-    const int lane = threadIdx.x, cpg = C / G;
+__global__ __launch_bounds__(256) void norm_finalize_bwd_kernel(const float* __restrict__ part, int Nb, int chunks, int C, int G,
+                                                                const float* __restrict__ gamma, float* __restrict__ ab,
+                                                                float* dgamma, float* dbeta) {
+    const int cpg = C / G;
     double s0 = 0.0, s1 = 0.0;
     if ((int)blockIdx.x < Nb * G) {
         const int i = blockIdx.x, n = i / G, g = i % G;
         const int items = chunks * cpg;
-        for (int e = lane; e < items; e += 64) {
+        for (int e = threadIdx.x; e < items; e += 256) {
             const int ch = e / cpg, c = g * cpg + e % cpg;
             const float* p = part + ((((long long)n * chunks + ch) * C) + c) * 2;
             const double gm = gamma ? (double)gamma[c] : 1.0;
             s0 += gm * p[0];
             s1 += gm * p[1];
         }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) { s0 += __shfl_xor(s0, o, 64); s1 += __shfl_xor(s1, o, 64); }
-        if (lane == 0) { ab[(long long)i * 2] = (float)s0; ab[(long long)i * 2 + 1] = (float)s1; }
+        block_sum2_double(s0, s1);
+        if (threadIdx.x == 0) { ab[(long long)i * 2] = (float)s0; ab[(long long)i * 2 + 1] = (float)s1; }
     } else {
         const int c = blockIdx.x - Nb * G;
         const int items = Nb * chunks;
-        for (int e = lane; e < items; e += 64) {
+        for (int e = threadIdx.x; e < items; e += 256) {
             const float* p = part + ((long long)e * C + c) * 2;   // (n, chunk) pairs are contiguous blocks of C
             s0 += p[0];
             s1 += p[1];
         }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) { s0 += __shfl_xor(s0, o, 64); s1 += __shfl_xor(s1, o, 64); }
-        if (lane == 0) { if (dbeta) dbeta[c] = (float)s0; if (dgamma) dgamma[c] = (float)s1; }
+        block_sum2_double(s0, s1);
+        if (threadIdx.x == 0) { if (dbeta) dbeta[c] = (float)s0; if (dgamma) dgamma[c] = (float)s1; }
     }
 }
 
@@ -356,7 +366,10 @@ __global__ __launch_bounds__(256) void norm_fused_fwd_kernel(T* __restrict__ X, 
         for (int q = 0; q < NVEC; ++q) {
             Vec16<T> x;
             if (SLAB) {
-                const long long off = ((long long)n * V + v) * C + c0 + q * VN;
+                // slabs are span-major (conv_gemm / conv_k3_tile with a deferred finish): [split][8-channel span][row][8] fp32, so the
+                // rows of this workgroup's span are one contiguous 32-byte-per-row run in every slab (VN == 8 here: bf16 only)
+                const long long Mrows = MN / C;
+                const long long off = ((long long)((c0 + q * VN) >> 3) * Mrows + (long long)n * V + v) * 8;
                 float f[VN];
 #pragma unroll
                 for (int k = 0; k < VN; ++k) f[k] = cbias ? cbias[c0 + q * VN + k] : 0.f;
@@ -577,7 +590,7 @@ extern "C" int dycon_norm_stats(const void* x, int dtype, int Nb, long long V, i
                                                             nullptr, nullptr, 0, 0, nullptr);
     });
     DYCON_LAUNCH_CHECK();
-    norm_finalize_stats_kernel<<<Nb * G, 64, 0, stream>>>(workspace, Nb, p.chunks, C, G, V, eps, stats, running_mean, running_var, momentum);
+    norm_finalize_stats_kernel<<<Nb * G, 256, 0, stream>>>(workspace, Nb, p.chunks, C, G, V, eps, stats, running_mean, running_var, momentum);
     DYCON_LAUNCH_CHECK();
     return DYCON_OK;
 }
@@ -635,6 +648,22 @@ extern "C" int dycon_norm_bwd(const void* src, int from_y, const void* gy, void*
                               int G, const float* stats, const float* gamma, const float* beta, int relu,
                               const float* chan_scale, float* dgamma, float* dbeta, float* workspace, size_t ws_bytes,
                               dycon_stream_t stream) {
+    return dycon_norm_bwd_ex(src, from_y, gy, gx, dtype, Nb, V, C, G, stats, gamma, beta, relu, chan_scale, dgamma, dbeta, 0, workspace,
+                             ws_bytes, stream);
+}
+
+// the per-sample {dbeta, dgamma} contributions a deferred one-launch backward left in its workspace -> dgamma / dbeta
+extern "C" int dycon_norm_sum_dparams(const float* workspace, int Nb, int C, float* dgamma, float* dbeta, dycon_stream_t stream) {
+    DYCON_REQUIRE(workspace && Nb > 0 && C > 0 && (dgamma || dbeta), "norm_sum_dparams: bad arguments");
+    norm_sum_dparams_kernel<<<cdiv(C, 256), 256, 0, stream>>>(workspace, Nb, C, dgamma, dbeta);
+    DYCON_LAUNCH_CHECK();
+    return DYCON_OK;
+}
+
+extern "C" int dycon_norm_bwd_ex(const void* src, int from_y, const void* gy, void* gx, int dtype, int Nb, long long V, int C,
+                                 int G, const float* stats, const float* gamma, const float* beta, int relu,
+                                 const float* chan_scale, float* dgamma, float* dbeta, int defer_dparams, float* workspace,
+                                 size_t ws_bytes, dycon_stream_t stream) {
     DYCON_REQUIRE(src && gy && gx && stats && workspace, "norm_bwd: null pointer");
     if (int e = norm_check("norm_bwd", dtype, Nb, V, C, G)) return e;
     DYCON_REQUIRE(ws_bytes >= dycon_norm_workspace(Nb, V, C), "norm_bwd: workspace too small");
@@ -653,7 +682,7 @@ extern "C" int dycon_norm_bwd(const void* src, int from_y, const void* gy, void*
         }
 #undef DYCON_NB
         DYCON_LAUNCH_CHECK();
-        if (want) {
+        if (want && !defer_dparams) {     // deferred: the caller sums them (dycon_norm_sum_dparams), possibly on another stream
             norm_sum_dparams_kernel<<<cdiv(C, 256), 256, 0, stream>>>(workspace, Nb, C, dgamma, dbeta);
             DYCON_LAUNCH_CHECK();
         }
@@ -668,7 +697,7 @@ extern "C" int dycon_norm_bwd(const void* src, int from_y, const void* gy, void*
     });
     DYCON_LAUNCH_CHECK();
     const int nfin = Nb * G + ((dgamma || dbeta) ? C : 0);
-    norm_finalize_bwd_kernel<<<nfin, 64, 0, stream>>>(workspace, Nb, p.chunks, C, G, gamma, ab, dgamma, dbeta);
+    norm_finalize_bwd_kernel<<<nfin, 256, 0, stream>>>(workspace, Nb, p.chunks, C, G, gamma, ab, dgamma, dbeta);
     DYCON_LAUNCH_CHECK();
     DYCON_DISPATCH(dtype, {
         dim3 grid2(apply_grid(V, C, Vec16<T>::N), Nb);

@@ -195,6 +195,7 @@ class Engine:
         # fp32 slabs in 32-byte pieces at a C*4-byte stride where splitk_finish streams them fully coalesced.  Off by default.
         self.fuse_finish = False
         self._deferred = {}
+        self._pending_dparams = []
         self.tape = []
         self.G = {}
 
@@ -366,6 +367,7 @@ class Engine:
                     ev, cs, ws_ = torch.cuda.Event(), ops.cur_stream(), self.wgrad_stream
                     ops.rec(lambda: (ev.record(cs), ws_.wait_event(ev)))
                     with ops.on_stream(self.wgrad_stream, light=True):
+                        self._flush_dparams()
                         wgrad(gy)
                     gy.record_stream(self.wgrad_stream)
                 else:
@@ -407,6 +409,13 @@ class Engine:
         a = self.acc_arena[self._acc_off:self._acc_off + n]
         self._acc_off += n
         return a
+
+    def _flush_dparams(self):
+        """deferred dgamma / dbeta sums of the norms whose backward has been enqueued (call inside the weight-gradient section)"""
+        for pend in self._pending_dparams:
+            ops.norm_sum_dparams(pend)
+            pend[0].record_stream(ops.cur_stream())
+        self._pending_dparams = []
 
     # ---------------------------------------------------------------- norm (+ReLU, +skip)
     def _norm(self, prefix, z, kind, relu=True, skip=None, training=True, chan_scale=None):
@@ -460,8 +469,17 @@ class Engine:
                 dg = self.g[prefix + ".weight"] if gamma is not None else None
                 db = self.g[prefix + ".bias"] if beta is not None else None
                 acc = None if ops.norm_fwd_is_fused(z, V, C, G) else self._acc(ops.query("dycon_norm_acc_doubles", Nb, V, C))
-                gz = gy if "norm_bwd" in ABLATE else ops.norm_bwd(z, False, gy, stats, Nb, V, C, G, gamma, beta, relu, dg, db,
-                                                                  chan_scale=chan_scale, acc=acc)
+                if "norm_bwd" in ABLATE:
+                    gz = gy
+                elif acc is None and self.wgrad_stream is not None and dg is not None:
+                    # one-launch shapes: the tiny sum of the per-sample dgamma / dbeta contributions leaves the dependent chain -- it
+                    # is enqueued on the weight-gradient stream by the convolution's backward that follows (same fork event)
+                    gz, pend = ops.norm_bwd(z, False, gy, stats, Nb, V, C, G, gamma, beta, relu, dg, db, chan_scale=chan_scale,
+                                            defer_dparams=True)
+                    if pend is not None:
+                        self._pending_dparams.append(pend)
+                else:
+                    gz = ops.norm_bwd(z, False, gy, stats, Nb, V, C, G, gamma, beta, relu, dg, db, chan_scale=chan_scale, acc=acc)
                 if self.on_param_grads is not None and gamma is not None:
                     self.on_param_grads(prefix + ".weight")
                 self._give(z, gz)
@@ -676,6 +694,11 @@ class Engine:
             else:
                 self.tape[i]()
         cs = ops.cur_stream()
+        if self._pending_dparams:                             # (a norm whose convolution does not run its weight gradient on the side stream)
+            ev, ws_ = torch.cuda.Event(), self.wgrad_stream
+            ops.rec(lambda: (ev.record(cs), ws_.wait_event(ev)))
+            with ops.on_stream(self.wgrad_stream, light=True):
+                self._flush_dparams()
         if self.mark is not None:                             # tools/timeline.py
             self.mark("bwd_chain_end", cs)
             if self.feat_stream is not None:

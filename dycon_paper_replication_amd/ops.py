@@ -356,7 +356,7 @@ def norm_apply(x, stats, Nb, V, C, G, gamma=None, beta=None, relu=True, skip=Non
 
 
 def norm_bwd(src, from_y, gy, stats, Nb, V, C, G, gamma=None, beta=None, relu=True, dgamma=None, dbeta=None, out=None,
-             chan_scale=None, acc=None):
+             chan_scale=None, acc=None, defer_dparams=False):
     if out is None:
         out = torch.empty_like(gy)
     if acc is not None and not from_y:
@@ -367,10 +367,19 @@ def norm_bwd(src, from_y, gy, stats, Nb, V, C, G, gamma=None, beta=None, relu=Tr
                  _p(chan_scale), _p(dgamma), _p(dbeta), _p(acc), _p(ws), ws.numel() * 4 if fused else 0, _s())
         return out
     ws = _ws(query("dycon_norm_workspace", Nb, V, C), gy)
+    deferred = bool(defer_dparams) and not from_y and (dgamma is not None or dbeta is not None) and norm_fwd_is_fused(gy, V, C, G)
     with _Region("norm_bwd", gy.numel() * _es(gy) * 5, 12 * gy.numel()):
-        call("dycon_norm_bwd", _p(src), int(from_y), _p(gy), _p(out), dt(gy), Nb, V, C, G, _p(stats), _p(gamma), _p(beta),
-             int(relu), _p(chan_scale), _p(dgamma), _p(dbeta), _p(ws), ws.numel() * 4, _s())
+        call("dycon_norm_bwd_ex", _p(src), int(from_y), _p(gy), _p(out), dt(gy), Nb, V, C, G, _p(stats), _p(gamma), _p(beta),
+             int(relu), _p(chan_scale), _p(dgamma), _p(dbeta), int(deferred), _p(ws), ws.numel() * 4, _s())
+    if defer_dparams:
+        return out, ((ws, Nb, C, dgamma, dbeta) if deferred else None)
     return out
+
+
+def norm_sum_dparams(pending):
+    """finish a deferred norm_bwd (ops.norm_bwd(..., defer_dparams=True)) on the CURRENT launch stream"""
+    ws, Nb, C, dgamma, dbeta = pending
+    call("dycon_norm_sum_dparams", _p(ws), Nb, C, _p(dgamma), _p(dbeta), _s())
 
 
 # ------------------------------------------------------------------ data movement / pointwise

@@ -69,6 +69,7 @@ class TrainConfig:
     overlap_teacher: bool = True        # teacher forward on a second HIP stream, concurrent with the student forward
     overlap_wgrad: bool = True          # weight-gradient launches of the backward on a second HIP stream (off the dgrad chain)
     overlap_features: bool = True       # feature branch (projection head, embeddings, FeCL forward + backward) on its own stream
+    fuse_finish: bool = False           # small levels: split-K finish of a convolution done by the one-launch norm that follows (Engine.fuse_finish)
     norm_accumulators: bool = False     # two-launch norms through double-atomic accumulators (measured slower: DESIGN.md section 9)
     replay: bool = True                 # after two eager steps of a given input signature, record the step's launch list once and
                                         # re-issue it with patched scalars (the step is host-enqueue-bound: see DyconTrainer.step);
@@ -129,6 +130,7 @@ class DyconTrainer:
         self.t_buf = dict(self.ema_model.named_buffers())
         self.s_eng = Engine(cfg.model, self.p, self.g, self.s_buf, cfg.dtype, cfg.feature_scaler, cfg.normalization)
         self.t_eng = Engine(cfg.model, self.t, None, self.t_buf, cfg.dtype, cfg.feature_scaler, cfg.normalization)
+        self.s_eng.fuse_finish = self.t_eng.fuse_finish = cfg.fuse_finish
         # accumulator form of the norms (engine.use_acc; measured slower, off by default): one arena of zeroed doubles per step,
         # shared by both nets and cleared by ONE launch at the start of the step, before the teacher stream forks
         self.acc_arena = None

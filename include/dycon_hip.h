@@ -149,6 +149,16 @@ int dycon_norm_bwd(const void* src, int from_y, const void* gy, void* gx, int dt
                    long long V, int C, int G, const float* stats, const float* gamma,
                    const float* beta, int relu, const float* chan_scale, float* dgamma, float* dbeta,
                    float* workspace, size_t ws_bytes, dycon_stream_t stream);
+/* dycon_norm_bwd with defer_dparams = 1: on the one-launch shapes (dycon_norm_fwd_is_fused) the per-sample {dbeta, dgamma}
+ * contributions stay in `workspace` ((Nb, C, 2) floats at its start) and the caller adds them up with dycon_norm_sum_dparams --
+ * e.g. on the weight-gradient stream: the parameter gradients only feed the optimiser, the data gradient is the dependent chain.
+ * Other shapes ignore the flag (their finalize launch writes dgamma / dbeta). */
+int dycon_norm_bwd_ex(const void* src, int from_y, const void* gy, void* gx, int dtype, int Nb,
+                      long long V, int C, int G, const float* stats, const float* gamma,
+                      const float* beta, int relu, const float* chan_scale, float* dgamma, float* dbeta,
+                      int defer_dparams, float* workspace, size_t ws_bytes, dycon_stream_t stream);
+int dycon_norm_sum_dparams(const float* workspace, int Nb, int C, float* dgamma, float* dbeta,
+                           dycon_stream_t stream);
 /* Accumulator forms of dycon_norm_fwd / dycon_norm_bwd (from_y = 0): `acc` = dycon_norm_acc_doubles(Nb, V, C) doubles that are
  * ZERO on entry (a slice of an arena the caller clears once per step).  On the shapes that are not served by the one-launch kernels, every chunk of the
  * statistics pass adds its sums to acc (double atomics) and the apply pass forms the group statistics in its prologue: TWO launches
