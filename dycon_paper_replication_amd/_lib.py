@@ -61,8 +61,8 @@ SIGNATURES = {
     "dycon_tanh": (I, [P, I, P, L, P]),
     "dycon_cast": (I, [P, I, P, I, L, P]),
     "dycon_add": (I, [P, P, P, I, L, P]),
-    "dycon_seg_losses_fwd": (I, [P, P, P, I, I, I, L, F, P, P]),
-    "dycon_seg_losses_bwd": (I, [P, P, P, I, I, I, L, F, P, P, I, P, P]),
+    "dycon_seg_losses_fwd": (I, [P, P, P, I, I, I, L, F, P, I, P]),
+    "dycon_seg_losses_bwd": (I, [P, P, P, I, I, I, L, F, P, P, I, P, I, P]),
     "dycon_seg_losses_finalize": (I, [P, I, I, L, F, P, P]),
     "dycon_step_loss": (I, [P, P, F, F, F, I, I, P, P, P]),
     "dycon_softmax_mse_fwd": (I, [P, P, P, L, I, L, I, P]),

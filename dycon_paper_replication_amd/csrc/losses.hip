@@ -11,19 +11,26 @@ __device__ __forceinline__ int load_label(const void* labels, int label_bytes, l
     return label_bytes == 8 ? (int)((const long long*)labels)[i] : (int)((const uint8_t*)labels)[i];
 }
 
+// FAST: hardware exp2/log2/rcp sequences (1-2 ulp) instead of the libm routines; the bf16 step uses them (its logits carry bf16
+// noise), the fp32 parity mode does not.  The voxel-loss kernels are bound by these sequences, not by their 60 MB of traffic.
+template <bool FAST> __device__ __forceinline__ float fexp(float x) { return FAST ? __expf(x) : expf(x); }
+template <bool FAST> __device__ __forceinline__ float flog(float x) { return FAST ? __logf(x) : logf(x); }
+template <bool FAST> __device__ __forceinline__ float fdiv(float a, float b) { return FAST ? __fdividef(a, b) : a / b; }
+
 struct Soft2 { float p0, p1, lse, m; };
-__device__ __forceinline__ Soft2 softmax2(float l0, float l1) {
+template <bool FAST> __device__ __forceinline__ Soft2 softmax2(float l0, float l1) {
     Soft2 s;
     s.m = fmaxf(l0, l1);
-    const float e0 = expf(l0 - s.m), e1 = expf(l1 - s.m), z = e0 + e1;
-    s.p0 = e0 / z;
-    s.p1 = e1 / z;
-    s.lse = logf(z);
+    const float e0 = fexp<FAST>(l0 - s.m), e1 = fexp<FAST>(l1 - s.m), z = e0 + e1;
+    s.p0 = fdiv<FAST>(e0, z);
+    s.p1 = fdiv<FAST>(e1, z);
+    s.lse = flog<FAST>(z);
     return s;
 }
 
 constexpr int NSUM = 11;
 
+template <bool FAST>
 __global__ __launch_bounds__(256) void seg_losses_fwd_kernel(const float2* __restrict__ SL, const float2* __restrict__ TL,
                                                              const void* __restrict__ labels, int label_bytes, int B, int LB,
                                                              long long V, float beta, double* __restrict__ sums) {
@@ -31,12 +38,11 @@ __global__ __launch_bounds__(256) void seg_losses_fwd_kernel(const float2* __res
     float acc[NSUM];
 #pragma unroll
     for (int k = 0; k < NSUM; ++k) acc[k] = 0.f;
-    const long long total = (long long)B * V;
+    const long long total = (long long)B * V, lab_end = (long long)LB * V;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-        const int b = (int)(i / V);
         const float2 ls = SL[i], lt = TL[i];
-        const Soft2 s = softmax2(ls.x, ls.y), t = softmax2(lt.x, lt.y);
-        if (b < LB) {
+        const Soft2 s = softmax2<FAST>(ls.x, ls.y), t = softmax2<FAST>(lt.x, lt.y);
+        if (i < lab_end) {
             const int y = load_label(labels, label_bytes, i);
             const float ly = y == 1 ? ls.y : ls.x;
             acc[0] += -(ly - s.m - s.lse);
@@ -45,17 +51,17 @@ __global__ __launch_bounds__(256) void seg_losses_fwd_kernel(const float2* __res
             acc[4] += s.p0 * t0; acc[5] += s.p0 * s.p0; acc[6] += t0;
         } else {
             // the reference feeds PROBABILITIES to softmax_mse_loss / softmax_kl_loss, which softmax again
-            const Soft2 qs = softmax2(s.p0, s.p1), qt = softmax2(t.p0, t.p1);
+            const Soft2 qs = softmax2<FAST>(s.p0, s.p1), qt = softmax2<FAST>(t.p0, t.p1);
             const float d0 = qs.p0 - qt.p0, d1 = qs.p1 - qt.p1;
             acc[7] += d0 * d0 + d1 * d1;
             const float lqs0 = s.p0 - qs.m - qs.lse, lqs1 = s.p1 - qs.m - qs.lse;
-            acc[8] += qt.p0 * (logf(qt.p0) - lqs0) + qt.p1 * (logf(qt.p1) - lqs1);
+            acc[8] += qt.p0 * (flog<FAST>(qt.p0) - lqs0) + qt.p1 * (flog<FAST>(qt.p1) - lqs1);
         }
-        const float hs = -(s.p0 * logf(s.p0 + 1e-6f) + s.p1 * logf(s.p1 + 1e-6f));
-        const float ht = -(t.p0 * logf(t.p0 + 1e-6f) + t.p1 * logf(t.p1 + 1e-6f));
-        const float w = expf(beta * hs) + expf(beta * ht);
+        const float hs = -(s.p0 * flog<FAST>(s.p0 + 1e-6f) + s.p1 * flog<FAST>(s.p1 + 1e-6f));
+        const float ht = -(t.p0 * flog<FAST>(t.p0 + 1e-6f) + t.p1 * flog<FAST>(t.p1 + 1e-6f));
+        const float w = fexp<FAST>(beta * hs) + fexp<FAST>(beta * ht);
         const float e0 = s.p0 - t.p0, e1 = s.p1 - t.p1;
-        acc[9] += (e0 * e0 + e1 * e1) / w;
+        acc[9] += fdiv<FAST>(e0 * e0 + e1 * e1, w);
         acc[10] += hs + ht;
     }
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -71,6 +77,7 @@ __global__ __launch_bounds__(256) void seg_losses_fwd_kernel(const float2* __res
     }
 }
 
+template <bool FAST>
 __global__ __launch_bounds__(256) void seg_losses_bwd_kernel(const float2* __restrict__ SL, const float2* __restrict__ TL,
                                                              const void* __restrict__ labels, int label_bytes, int B, int LB,
                                                              long long V, float beta, const double* __restrict__ sums,
@@ -83,24 +90,24 @@ __global__ __launch_bounds__(256) void seg_losses_bwd_kernel(const float2* __res
     const float inv_ce = LB > 0 ? 1.f / ((float)LB * (float)V) : 0.f;
     const float inv_cons = B > LB ? 1.f / ((float)(B - LB) * (float)V * 2.f) : 0.f;
     const float inv_all = 1.f / ((float)B * (float)V);
-    const long long total = (long long)B * V;
+    const float inv_D1sq = 1.f / (D1 * D1), inv_D0sq = 1.f / (D0 * D0);
+    const long long total = (long long)B * V, lab_end = (long long)LB * V;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-        const int b = (int)(i / V);
         const float2 ls = SL[i], lt = TL[i];
-        const Soft2 s = softmax2(ls.x, ls.y), t = softmax2(lt.x, lt.y);
+        const Soft2 s = softmax2<FAST>(ls.x, ls.y), t = softmax2<FAST>(lt.x, lt.y);
         float gp0 = 0.f, gp1 = 0.f;   // d loss / d student probabilities
         float gl0 = 0.f, gl1 = 0.f;   // direct d loss / d logits (cross entropy)
-        if (b < LB) {
+        if (i < lab_end) {
             const int y = load_label(labels, label_bytes, i);
             const float t1 = y == 1 ? 1.f : 0.f, t0 = y == 0 ? 1.f : 0.f;
             gl0 = c_ce * inv_ce * (s.p0 - t0);
             gl1 = c_ce * inv_ce * (s.p1 - t1);
-            const float dd1 = -(2.f * t1 * D1 - (2.f * I1 + smooth) * 2.f * s.p1) / (D1 * D1);
-            const float dd0 = -(2.f * t0 * D0 - (2.f * I0 + smooth) * 2.f * s.p0) / (D0 * D0);
+            const float dd1 = -(2.f * t1 * D1 - (2.f * I1 + smooth) * 2.f * s.p1) * inv_D1sq;
+            const float dd0 = -(2.f * t0 * D0 - (2.f * I0 + smooth) * 2.f * s.p0) * inv_D0sq;
             gp1 += c_dfg * dd1 + 0.5f * c_dmc * dd1;
             gp0 += 0.5f * c_dmc * dd0;
         } else {
-            const Soft2 qs = softmax2(s.p0, s.p1), qt = softmax2(t.p0, t.p1);
+            const Soft2 qs = softmax2<FAST>(s.p0, s.p1), qt = softmax2<FAST>(t.p0, t.p1);
             float gq0, gq1;   // gradient w.r.t. the inner softmax INPUT (= student probabilities)
             if (cons_kind == 0) {
                 const float a0 = 2.f * (qs.p0 - qt.p0) * inv_cons, a1 = 2.f * (qs.p1 - qt.p1) * inv_cons;
@@ -116,14 +123,15 @@ __global__ __launch_bounds__(256) void seg_losses_bwd_kernel(const float2* __res
         }
         {
             const float eps = 1e-6f;
-            const float hs = -(s.p0 * logf(s.p0 + eps) + s.p1 * logf(s.p1 + eps));
-            const float ht = -(t.p0 * logf(t.p0 + eps) + t.p1 * logf(t.p1 + eps));
-            const float ehs = expf(beta * hs), w = ehs + expf(beta * ht);
+            const float hs = -(s.p0 * flog<FAST>(s.p0 + eps) + s.p1 * flog<FAST>(s.p1 + eps));
+            const float ht = -(t.p0 * flog<FAST>(t.p0 + eps) + t.p1 * flog<FAST>(t.p1 + eps));
+            const float ehs = fexp<FAST>(beta * hs), w = ehs + fexp<FAST>(beta * ht);
             const float e0 = s.p0 - t.p0, e1 = s.p1 - t.p1, d2 = e0 * e0 + e1 * e1;
-            const float dh0 = -(logf(s.p0 + eps) + s.p0 / (s.p0 + eps)), dh1 = -(logf(s.p1 + eps) + s.p1 / (s.p1 + eps));
-            const float k = beta - d2 * beta * ehs / (w * w);
-            gp0 += c_uncl * inv_all * (2.f * e0 / w + dh0 * k);
-            gp1 += c_uncl * inv_all * (2.f * e1 / w + dh1 * k);
+            const float dh0 = -(flog<FAST>(s.p0 + eps) + fdiv<FAST>(s.p0, s.p0 + eps)), dh1 = -(flog<FAST>(s.p1 + eps) + fdiv<FAST>(s.p1, s.p1 + eps));
+            const float rw = fdiv<FAST>(1.f, w);
+            const float k = beta - d2 * beta * ehs * rw * rw;
+            gp0 += c_uncl * inv_all * (2.f * e0 * rw + dh0 * k);
+            gp1 += c_uncl * inv_all * (2.f * e1 * rw + dh1 * k);
         }
         const float dot = s.p0 * gp0 + s.p1 * gp1;
         G[i] = make_float2(gl0 + s.p0 * (gp0 - dot), gl1 + s.p1 * (gp1 - dot));
@@ -362,9 +370,6 @@ __device__ __forceinline__ float row16_max(float v) {
 
 // fp32 storage (parity mode): IEEE expf/logf/division.  bf16 storage: hardware v_exp/v_log/v_rcp forms (1e-6 relative,
 // far below the bf16 rounding of the operands) -- the pair epilogue is the VALU-bound part of FeCL.
-template <bool FAST> __device__ __forceinline__ float fexp(float x) { return FAST ? __expf(x) : expf(x); }
-template <bool FAST> __device__ __forceinline__ float flog(float x) { return FAST ? __logf(x) : logf(x); }
-template <bool FAST> __device__ __forceinline__ float fdiv(float a, float b) { return FAST ? __fdividef(a, b) : a / b; }
 
 // d/dP of phi(P) = -log(P+eps) * (1-P)^gamma   (gamma = 0 <=> no focal weight)
 template <bool FAST>
@@ -736,28 +741,32 @@ static inline int lgrid(long long n) {
 }
 
 extern "C" int dycon_seg_losses_fwd(const float* s_logits, const float* t_logits, const void* labels, int label_bytes, int B,
-                                    int LB, long long V, float beta, double* sums, dycon_stream_t stream) {
+                                    int LB, long long V, float beta, double* sums, int fast, dycon_stream_t stream) {
     DYCON_REQUIRE(s_logits && t_logits && sums && B > 0 && LB >= 0 && LB <= B && V > 0, "seg_losses_fwd: bad arguments");
     DYCON_REQUIRE(LB == 0 || labels, "seg_losses_fwd: labels missing");
     DYCON_REQUIRE(label_bytes == 1 || label_bytes == 8, "seg_losses_fwd: labels must be uint8 or int64");
     if (hipMemsetAsync(sums, 0, 16 * sizeof(double), stream) != hipSuccess) { dycon_set_error("seg_losses_fwd: memset failed"); return DYCON_ERR_LAUNCH; }
-    // 512 workgroups (two per CU): every workgroup ends with 11 double atomics onto the same 11 addresses, and same-address
-    // atomics serialise at the memory side -- with 2048 workgroups that tail was most of the kernel (77 us for 60 MB)
-    const long long wg = ((long long)B * V + 255) / 256;
-    seg_losses_fwd_kernel<<<(int)(wg < 512 ? (wg < 1 ? 1 : wg) : 512), 256, 0, stream>>>((const float2*)s_logits, (const float2*)t_logits, labels,
-                                                                       label_bytes, B, LB, V, beta, sums);
+    // grid: as many waves in flight as the chip holds -- the kernel is bound by its exp / log sequences (a 512-workgroup grid that
+    // thinned the 11 same-address double atomics per workgroup was 1.5x SLOWER)
+    const int grid = lgrid((long long)B * V);
+    if (fast)
+        seg_losses_fwd_kernel<true><<<grid, 256, 0, stream>>>((const float2*)s_logits, (const float2*)t_logits, labels, label_bytes, B, LB, V, beta, sums);
+    else
+        seg_losses_fwd_kernel<false><<<grid, 256, 0, stream>>>((const float2*)s_logits, (const float2*)t_logits, labels, label_bytes, B, LB, V, beta, sums);
     DYCON_LAUNCH_CHECK();
     return DYCON_OK;
 }
 
 extern "C" int dycon_seg_losses_bwd(const float* s_logits, const float* t_logits, const void* labels, int label_bytes, int B,
                                     int LB, long long V, float beta, const double* sums, const float* coef, int cons_kind,
-                                    float* g_logits, dycon_stream_t stream) {
+                                    float* g_logits, int fast, dycon_stream_t stream) {
     DYCON_REQUIRE(s_logits && t_logits && sums && coef && g_logits && B > 0 && LB >= 0 && LB <= B && V > 0, "seg_losses_bwd: bad arguments");
     DYCON_REQUIRE(label_bytes == 1 || label_bytes == 8, "seg_losses_bwd: labels must be uint8 or int64");
-    seg_losses_bwd_kernel<<<lgrid((long long)B * V), 256, 0, stream>>>((const float2*)s_logits, (const float2*)t_logits, labels,
-                                                                       label_bytes, B, LB, V, beta, sums, coef, cons_kind,
-                                                                       (float2*)g_logits);
+    const int grid = lgrid((long long)B * V);
+    if (fast)
+        seg_losses_bwd_kernel<true><<<grid, 256, 0, stream>>>((const float2*)s_logits, (const float2*)t_logits, labels, label_bytes, B, LB, V, beta, sums, coef, cons_kind, (float2*)g_logits);
+    else
+        seg_losses_bwd_kernel<false><<<grid, 256, 0, stream>>>((const float2*)s_logits, (const float2*)t_logits, labels, label_bytes, B, LB, V, beta, sums, coef, cons_kind, (float2*)g_logits);
     DYCON_LAUNCH_CHECK();
     return DYCON_OK;
 }

@@ -497,21 +497,21 @@ def _label_bytes(labels):
     raise TypeError("labels must be int64 or uint8")
 
 
-def seg_losses_fwd(s_logits, t_logits, labels, LB, beta):
-    """s/t_logits: (B, D, H, W, 2) fp32; returns sums (16 doubles on device)."""
+def seg_losses_fwd(s_logits, t_logits, labels, LB, beta, fast=False):
+    """s/t_logits: (B, D, H, W, 2) fp32; returns sums (16 doubles on device).  fast: hardware exp/log sequences (bf16 step)."""
     B = s_logits.shape[0]
     V = s_logits.numel() // (2 * B)
     sums = torch.empty(16, dtype=torch.float64, device=s_logits.device)
-    call("dycon_seg_losses_fwd", _p(s_logits), _p(t_logits), _p(labels), _label_bytes(labels), B, LB, V, float(beta), _p(sums), _s())
+    call("dycon_seg_losses_fwd", _p(s_logits), _p(t_logits), _p(labels), _label_bytes(labels), B, LB, V, float(beta), _p(sums), int(fast), _s())
     return sums
 
 
-def seg_losses_bwd(s_logits, t_logits, labels, LB, beta, sums, coef, cons_kind=0):
+def seg_losses_bwd(s_logits, t_logits, labels, LB, beta, sums, coef, cons_kind=0, fast=False):
     B = s_logits.shape[0]
     V = s_logits.numel() // (2 * B)
     g = torch.empty_like(s_logits)
     call("dycon_seg_losses_bwd", _p(s_logits), _p(t_logits), _p(labels), _label_bytes(labels), B, LB, V, float(beta), _p(sums),
-         _p(coef), cons_kind, _p(g), _s())
+         _p(coef), cons_kind, _p(g), int(fast), _s())
     return g
 
 

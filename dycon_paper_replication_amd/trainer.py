@@ -128,6 +128,7 @@ class DyconTrainer:
                     b.copy_(init[k].to(self.device))
         self.s_buf = dict(self.model.named_buffers())
         self.t_buf = dict(self.ema_model.named_buffers())
+        self._fast_math = cfg.dtype == torch.bfloat16     # voxel-loss exp / log by the hardware sequences; fp32 = parity mode, libm
         self.s_eng = Engine(cfg.model, self.p, self.g, self.s_buf, cfg.dtype, cfg.feature_scaler, cfg.normalization)
         self.t_eng = Engine(cfg.model, self.t, None, self.t_buf, cfg.dtype, cfg.feature_scaler, cfg.normalization)
         self.s_eng.fuse_finish = self.t_eng.fuse_finish = cfg.fuse_finish
@@ -381,7 +382,7 @@ class DyconTrainer:
         # ---- losses (:308-357)
         world = self.world
         glob = world > 1 and c.global_batch_losses
-        sums = ops.seg_losses_fwd(s_logits, t_logits, label, LB, beta)
+        sums = ops.seg_losses_fwd(s_logits, t_logits, label, LB, beta, fast=self._fast_math)
         fctx = (lambda: ops.on_stream(self.feat)) if self.feat is not None else contextlib.nullcontext
         with fctx():
             if self.feat is not None:                     # teacher features (the student's head was enqueued on self.feat)
@@ -421,7 +422,7 @@ class DyconTrainer:
         ops.set_scalars(self.coef, [c.l_weight, c.l_weight * (1 - dice_kind) * gw, c.l_weight * dice_kind * gw, cw,
                                     c.u_weight, c.u_weight])
         self._mark("loss_end")
-        g_logits = ops.seg_losses_bwd(s_logits, t_logits, label, LB, beta, sums, self.coef, cons_kind)
+        g_logits = ops.seg_losses_bwd(s_logits, t_logits, label, LB, beta, sums, self.coef, cons_kind, fast=self._fast_math)
         if self.feat is not None:
             ops.rec(lambda: feat.wait_stream(main))       # coef (and, with DDP, the all-reduced FeCL sums)
         with fctx():

@@ -227,16 +227,19 @@ int dycon_add(const void* a, const void* b, void* y, int dtype, long long n, dyc
  * step needs (train_DyCON_BraTS19.py:308-314,351-352; utils/losses.py:8-16,65-104,156-192;
  * utils/dycon_losses.py:94-118) into sums[16] (double, zeroed by the call):
  *   0 ce_sum   1 I1  2 Z1  3 Y1   4 I0  5 Z0  6 Y0   7 mse_sum  8 kl_sum  9 uncl_w  10 uncl_h
- * samples [0,LB) are labelled (CE, Dice), [LB,B) feed the consistency term, all feed UnCL. */
+ * samples [0,LB) are labelled (CE, Dice), [LB,B) feed the consistency term, all feed UnCL.
+ * fast != 0: hardware exp2 / log2 / rcp sequences (1-2 ulp) instead of the libm routines -- for
+ * logits that come out of a bf16 network; the fp32 parity mode passes 0. */
 int dycon_seg_losses_fwd(const float* s_logits, const float* t_logits, const void* labels,
                          int label_bytes, int B, int LB, long long V, float beta, double* sums,
-                         dycon_stream_t stream);
+                         int fast, dycon_stream_t stream);
 /* g_logits = sum_k coef[k] * d(loss_k)/d(s_logits); coef (device, 5 floats): ce, dice_fg,
  * dice_multiclass, consistency (mse or kl per cons_kind), uncl -- already multiplied by the
  * upstream gradient.  Needs the sums from the forward call. */
 int dycon_seg_losses_bwd(const float* s_logits, const float* t_logits, const void* labels,
                          int label_bytes, int B, int LB, long long V, float beta, const double* sums,
-                         const float* coef, int cons_kind, float* g_logits, dycon_stream_t stream);
+                         const float* coef, int cons_kind, float* g_logits, int fast,
+                         dycon_stream_t stream);
 
 /* vals[6] (device floats) = ce, dice(class 1), dice(mean over classes), cons mse, cons kl, uncl */
 int dycon_seg_losses_finalize(const double* sums, int B, int LB, long long V, float beta, float* vals,

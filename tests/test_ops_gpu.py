@@ -292,46 +292,51 @@ def test_pointwise():
     close(ops.add_noise(torch.ones(1000, device=DEV), ex), 1 + ex, 1e-6, 1e-7)
 
 
+@pytest.mark.parametrize("fast", [False, True])
 @pytest.mark.parametrize("tag", ["a", "b", "c"])
-def test_uncl_golden(tag):
+def test_uncl_golden(tag, fast):
+    """fast = the hardware exp2 / log2 / rcp sequences the bf16 step uses: same fixtures, 10x the tolerance"""
     g = load_golden(f"uncl_{tag}")
     s, t = nd(T(g["s"])), nd(T(g["t"]))
     B = s.shape[0]
     V = s.numel() // (2 * B)
+    k = 10.0 if fast else 1.0
     lab = torch.zeros(s.shape[:4], dtype=torch.uint8, device=DEV)
     for i, beta in enumerate(g["betas"]):
-        sums = ops.seg_losses_fwd(s, t, lab, 0, float(beta))
+        sums = ops.seg_losses_fwd(s, t, lab, 0, float(beta), fast=fast)
         vals = ops.seg_losses_finalize(sums, B, 0, V, float(beta))
-        close(vals[5], g[f"loss{i}"], 1e-5, 1e-6)
+        close(vals[5], g[f"loss{i}"], k * 1e-5, 1e-6)
         coef = torch.tensor([0, 0, 0, 0, 1.0], device=DEV)
-        gs = ops.seg_losses_bwd(s, t, lab, 0, float(beta), sums, coef)
-        close(nc(gs), g[f"grad{i}"], 1e-4, 1e-8)
+        gs = ops.seg_losses_bwd(s, t, lab, 0, float(beta), sums, coef, fast=fast)
+        close(nc(gs), g[f"grad{i}"], k * 1e-4, k * 1e-8)
 
 
-def test_voxel_losses_golden():
+@pytest.mark.parametrize("fast", [False, True])
+def test_voxel_losses_golden(fast):
     g = load_golden("voxel_losses")
     a, b, lab = T(g["a"]), T(g["b"]), T(g["label"])
     B = a.shape[0]
     V = a.numel() // (2 * B)
+    k = 10.0 if fast else 1.0
     ad, labd = nd(a), lab.to(DEV)
     # labelled terms: every sample labelled (LB = B)
-    sums = ops.seg_losses_fwd(ad, nd(b), labd, B, 1.0)
+    sums = ops.seg_losses_fwd(ad, nd(b), labd, B, 1.0, fast=fast)
     vals = ops.seg_losses_finalize(sums, B, B, V, 1.0)
-    close(vals[0], g["ce"], 1e-5, 1e-6)
-    close(vals[1], g["dice"], 1e-5, 1e-6)
-    close(vals[2], g["dice_mc"], 1e-5, 1e-6)
-    for k, key in ((0, "ce_grad"), (1, "dice_grad"), (2, "dice_mc_grad")):
+    close(vals[0], g["ce"], k * 1e-5, 1e-6)
+    close(vals[1], g["dice"], k * 1e-5, 1e-6)
+    close(vals[2], g["dice_mc"], k * 1e-5, 1e-6)
+    for j, key in ((0, "ce_grad"), (1, "dice_grad"), (2, "dice_mc_grad")):
         coef = torch.zeros(5, device=DEV)
-        coef[k] = 1
-        close(nc(ops.seg_losses_bwd(ad, nd(b), labd, B, 1.0, sums, coef)), g[key], 1e-4, 1e-8, key)
+        coef[j] = 1
+        close(nc(ops.seg_losses_bwd(ad, nd(b), labd, B, 1.0, sums, coef, fast=fast)), g[key], k * 1e-4, k * 1e-8, key)
     # consistency terms: no sample labelled (LB = 0); uint8 labels exercise the other label path
-    sums = ops.seg_losses_fwd(ad, nd(b), labd.to(torch.uint8), 0, 1.0)
+    sums = ops.seg_losses_fwd(ad, nd(b), labd.to(torch.uint8), 0, 1.0, fast=fast)
     vals = ops.seg_losses_finalize(sums, B, 0, V, 1.0)
-    close(vals[3], g["cons_mse"], 1e-5, 1e-7)
-    close(vals[4], g["cons_kl"], 1e-4, 1e-7)
+    close(vals[3], g["cons_mse"], k * 1e-5, 1e-7)
+    close(vals[4], g["cons_kl"], k * 1e-4, 1e-7)
     coef = torch.tensor([0, 0, 0, 1.0, 0], device=DEV)
-    close(nc(ops.seg_losses_bwd(ad, nd(b), labd.to(torch.uint8), 0, 1.0, sums, coef, 0)), g["cons_mse_grad"], 1e-4, 1e-9)
-    close(nc(ops.seg_losses_bwd(ad, nd(b), labd.to(torch.uint8), 0, 1.0, sums, coef, 1)), g["cons_kl_grad"], 1e-4, 1e-9)
+    close(nc(ops.seg_losses_bwd(ad, nd(b), labd.to(torch.uint8), 0, 1.0, sums, coef, 0, fast=fast)), g["cons_mse_grad"], k * 1e-4, k * 1e-9)
+    close(nc(ops.seg_losses_bwd(ad, nd(b), labd.to(torch.uint8), 0, 1.0, sums, coef, 1, fast=fast)), g["cons_kl_grad"], k * 1e-4, k * 1e-9)
 
 
 @pytest.mark.parametrize("tag", ["small", "mid", "oneclass", "singleton", "ragged"])
