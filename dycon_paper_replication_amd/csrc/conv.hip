@@ -877,6 +877,262 @@ __global__ __launch_bounds__(256, P16_WGS) void conv_k3_p16_kernel(const bf16* _
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The 48^3 level (32 -> 32 channels, 1728 tiles at B = 4): persistent k=3 kernel with the weights stationary in LDS.
+//
+// conv_k3_lds_kernel runs this shape as 1728 one-tile workgroups in 3.4 rounds of 2 per CU; every one of them pays an exposed
+// halo round trip, three restages of the 55 KB weight tensor through registers and LDS with two barriers each, and an epilogue
+// nothing overlaps.  Here ONE workgroup per CU
+//   * copies the whole packed weight tensor (27 taps x 32 x 32 bf16 = 55 KB) into LDS once,
+//   * walks ~7 tiles of its XCD's contiguous range with TWO halo images (38 KB each, the conflict-free rotated layout of
+//     conv_k3_lds_kernel<32,..>): the next tile's halo is requested before the current tile's MFMAs and written into the other
+//     image half-way through them -- one barrier per tile,
+//   * runs the MFMAs transposed (A = weights, B = voxels): a lane then holds 4 consecutive output channels of one voxel and
+//     stores them as 8 bytes straight from its accumulators -- no output staging through LDS,
+//   * resolves the zero padding with one tile-uniform bit mask (valid z / y / x halo coordinates) against a per-piece constant:
+//     boundary tiles (63 % of the tiles at 48^3) take the same path as inner ones.
+// Per tile and wave: 27 k-steps of 4 + 2 ds_read_b128 for 8 MFMAs.  132 KB LDS, 1 workgroup per CU.
+// ------------------------------------------------------------------------------------------------
+constexpr int P32_VS = 32;                                   // LDS voxel stride in elements (64 B)
+constexpr int P32_RP = CL_HX;                                // x-row pitch in voxels
+constexpr int P32_XH = CL_HZ * CL_HY * P32_RP * P32_VS;      // one halo image, bf16 elements (38.4 KB)
+constexpr int P32_BS = 27 * 2 * 64 * 8;                      // packed weights [tap][n-tile][lane][8] (55.3 KB)
+#ifndef P32_LA
+#define P32_LA 2                                             // LDS fragment reads run this many taps ahead of their MFMAs
+#endif
+#ifndef P32_BREG
+#define P32_BREG 0                                           // 1: all 54 weight fragments in registers instead of LDS (measured: 32.8 vs 30.5 us)
+#endif
+#ifndef P32_PIN
+#define P32_PIN 1                                            // halo pieces pinned inside their taps (0: the compiler places them)
+#endif
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void st8_untracked(void* p, unsigned lo, unsigned hi) {      // see st16_untracked
+    const u32x2 q = {lo, hi};
+    asm volatile("global_store_dwordx2 %0, %1, off" : : "v"(p), "v"(q) : "memory");
+}
+__device__ __forceinline__ unsigned pack_bf16x2(float a, float b) {                     // v_cvt_pk_bf16_f32
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{a, b}, bf16x2));
+}
+
+#ifdef P32_STAMP       // diagnostic builds only (tools/p32_stamps.py): where workgroup 0 / wave 0 spends its cycles, summed over its tiles
+__device__ unsigned long long p32_stamps[8];
+#define P32_T(var) unsigned long long var; __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var) :: "memory"); __builtin_amdgcn_sched_barrier(0)
+extern "C" int dycon_debug_p32_stamps(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(p32_stamps), sizeof(p32_stamps)); }
+#else
+#define P32_T(var)
+#endif
+
+struct P32Geo {             // wave-uniform description of one tile
+    long long org;          // element offset of voxel (b, z0, y0, x0), 32 channels per voxel
+    int z0, y0, x0;
+    unsigned mask;          // bit hz: halo z valid | bit 6 + hy | bit 16 + hx
+};
+
+__global__ __launch_bounds__(256, 1) void conv_k3_p32_kernel(const bf16* __restrict__ X, const bf16* __restrict__ Wf,
+                                                             const float* __restrict__ bias, bf16* __restrict__ Y, int B, int D,
+                                                             int H, int W, int tilesZ, int tilesY, int tilesX, int nTiles) {
+    __shared__ __attribute__((aligned(16))) unsigned short Xh[2 * P32_XH];
+#if !P32_BREG
+    __shared__ __attribute__((aligned(16))) unsigned short Bs[P32_BS];
+#endif
+    int tile, t_end, t_stride;
+    xcd_tile_range(nTiles, tile, t_end, t_stride);
+    if (tile >= t_end) return;                               // (uniform)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 15, kg = lane >> 4;
+#ifdef P32_STAMP
+    unsigned long long seg[6] = {0, 0, 0, 0, 0, 0};
+    P32_T(k0);
+#endif
+#if P32_BREG
+    // weights: all 54 B fragments (27 taps x 2 n-tiles) stay in this wave's registers for the lifetime of the workgroup -- with one
+    // wave per SIMD the 512-entry register file has room, and the LDS array serves A fragments only (4 instead of 6 reads per tap)
+    bf16x8 bw[27][2];
+#pragma unroll
+    for (int t = 0; t < 27; ++t)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            bw[t][j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(Wf + ((long long)(t * 2 + j) * 64 + lane) * 8));
+#else
+    // weights: every piece of this thread in flight at once (the packed order IS the fragment order: a linear copy)
+    constexpr int NWP = P32_BS / 8;                          // 3456 pieces of 16 B
+    constexpr int NWS = (NWP + 255) / 256;                   // 14 per thread
+    uint4 wst[NWS];
+#pragma unroll
+    for (int it = 0; it < NWS; ++it) wst[it] = *reinterpret_cast<const uint4*>(Wf + (long long)min((int)threadIdx.x + 256 * it, NWP - 1) * 8);
+#endif
+
+    // A fragments (the MFMA's B operand): wave w owns z-slice w of the tile, m-tile m = y rows 2m, 2m+1; k-step t = tap t, lane group
+    // kg reads the 8-channel chunk kg of voxel (x + dx), which sits at rotated position (kg + hx) & 3 of that voxel's 64 bytes.
+    constexpr int MSTEP = 2 * P32_RP * P32_VS;
+    int abase[3];
+    {
+        const int vb = ((wave * CL_HY + (r >> 3)) * P32_RP + (r & 7)) * P32_VS;
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) abase[dx] = vb + dx * P32_VS + 8 * ((kg + (r & 7) + dx) & 3);
+    }
+    const int bbase = lane * 8;
+
+    constexpr int NPC = CL_NH * 4;                           // 2400 halo pieces of 16 B
+    constexpr int NST = (NPC + 255) / 256;                   // per thread (10; pieces past the end duplicate the last one)
+    int rel[NST], lofs[NST];
+    unsigned need[NST];
+#pragma unroll
+    for (int it = 0; it < NST; ++it) {
+        const int e = min((int)threadIdx.x + 256 * it, NPC - 1);
+        const int hv = e >> 2, pc = e & 3;
+        const int hx = hv % CL_HX, hy = (hv / CL_HX) % CL_HY, hz = hv / (CL_HX * CL_HY);
+        rel[it] = (((hz - 1) * H + (hy - 1)) * W + (hx - 1)) * 32 + 8 * pc;
+        lofs[it] = ((hv / CL_HX) * P32_RP + hx) * P32_VS + 8 * ((pc + hx) & 3);
+        need[it] = (1u << hz) | (1u << (6 + hy)) | (1u << (16 + hx));
+    }
+    // output: lane (r, kg) holds channels 4 kg .. 4 kg + 3 (+16 for the second n-tile) of voxel r of each of its 4 m-tiles
+    const int obase = ((wave * H + (r >> 3)) * W + (r & 7)) * 32 + 4 * kg;
+    const int ostep = 2 * W * 32;
+    float bv[2][4];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) bv[j][i] = bias ? bias[j * 16 + 4 * kg + i] : 0.f;
+
+    auto geometry = [&](int t, P32Geo& g) {                  // scalar: tile index -> origin and validity mask (clamped past the end)
+        t = min(t, t_end - 1);
+        const int tx = t % tilesX; t /= tilesX;
+        const int ty = t % tilesY; t /= tilesY;
+        const int tz = t % tilesZ;
+        const int b = t / tilesZ;
+        g.z0 = tz * CL_TZ; g.y0 = ty * CL_TY; g.x0 = tx * CL_TX;
+        g.org = ((((long long)b * D + g.z0) * H + g.y0) * W + g.x0) * 32;
+        // valid halo coordinates h: 0 <= c0 + h - 1 < extent  <=>  h in [max(0, 1 - c0), min(n, extent - c0 + 1))
+        auto bits = [](int c0, int extent, int n) {
+            const int lo = c0 >= 1 ? 0 : 1, hi = min(n, extent - c0 + 1);
+            return ((1u << hi) - 1u) & ~((1u << lo) - 1u);
+        };
+        g.mask = bits(g.z0, D, CL_HZ) | (bits(g.y0, H, CL_HY) << 6) | (bits(g.x0, W, CL_HX) << 16);
+    };
+    // Halo loads are UNCONDITIONAL: a piece outside the volume reads the tile's origin voxel instead (a valid address) and is
+    // zeroed when it is written to LDS, so every wave issues exactly NST loads per tile (counted vmcnt waits)
+    auto load_piece = [&](const P32Geo& g, int it, uint4 (&stg)[NST]) {
+        const bool in = (g.mask & need[it]) == need[it];
+        stg[it] = *reinterpret_cast<const uint4*>(X + g.org + (in ? rel[it] : 0));
+    };
+    auto store_piece = [&](const P32Geo& g, int it, const uint4 (&stg)[NST], unsigned short* img) {
+        const bool in = (g.mask & need[it]) == need[it];
+        uint4 v = stg[it];
+        if (!in) v = make_uint4(0, 0, 0, 0);
+        *reinterpret_cast<uint4*>(img + lofs[it]) = v;
+    };
+
+    // One tile.  Halo pieces of the two tiles ahead travel in two register sets: set `ld` receives tile n+2 during taps 0..9 (one
+    // piece per tap), set `st` -- requested a whole tile ago -- is written into the other image during taps 10..19.  Each piece
+    // is pinned inside its tap (sched_barrier), so that its address arithmetic, its load issue or LDS write fills the
+    // vector-issue slots the tap's 8 MFMAs leave free: with one wave per SIMD nothing else would.
+    auto one_tile = [&](int cur, const P32Geo& gcur, const P32Geo& gst, const uint4 (&st)[NST], P32Geo& gld, uint4 (&ld)[NST], int buf) {
+        P32_T(t0);
+        const unsigned short* xh = Xh + buf * P32_XH;
+        unsigned short* xo = Xh + (buf ^ 1) * P32_XH;
+        geometry(cur + 2 * t_stride, gld);                   // (past the end: the last tile again -- loaded and written, never used)
+        f32x4 acc[4][2];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) { acc[m][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[m][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        constexpr int LA = P32_LA, RING = P32_LA + 1;        // fragments of tap t+LA are requested before the MFMAs of tap t
+        bf16x8 afr[RING][4];
+#if !P32_BREG
+        bf16x8 bfr[RING][2];
+#endif
+        auto fetch = [&](int n) {
+            const int imm = ((n / 9) * CL_HY + (n / 3) % 3) * P32_RP * P32_VS;
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+                afr[n % RING][m] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(xh + abase[n % 3] + imm + m * MSTEP));
+#if !P32_BREG
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                bfr[n % RING][j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(Bs + bbase + (n * 2 + j) * 512));
+#endif
+        };
+#pragma unroll
+        for (int n = 0; n < LA; ++n) fetch(n);
+#pragma unroll
+        for (int t = 0; t < 27; ++t) {
+            if (t + LA < 27) fetch(t + LA);
+            if (t < NST) load_piece(gld, t, ld);
+            else if (t < 2 * NST) store_piece(gst, t - NST, st, xo);
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)   // transposed: D[cout 4 kg + i][voxel r]
+#if P32_BREG
+                    acc[m][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bw[t][j], afr[t % RING][m], acc[m][j], 0, 0, 0);
+#else
+                    acc[m][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[t % RING][j], afr[t % RING][m], acc[m][j], 0, 0, 0);
+#endif
+#if P32_PIN
+            if (t < 2 * NST) __builtin_amdgcn_sched_barrier(0);
+#endif
+        }
+        P32_T(t4);
+        {
+            bf16* yb = Y + gcur.org + obase;
+            const bool zok = gcur.z0 + wave < D, xok = gcur.x0 + (r & 7) < W;
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                if (zok && xok && gcur.y0 + 2 * m + (r >> 3) < H) {
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        st8_untracked(yb + m * ostep + 16 * j, pack_bf16x2(acc[m][j][0] + bv[j][0], acc[m][j][1] + bv[j][1]),
+                                      pack_bf16x2(acc[m][j][2] + bv[j][2], acc[m][j][3] + bv[j][3]));
+                }
+            }
+        }
+        P32_T(t5);
+        __syncthreads();                                     // this tile's image consumed, the next one complete
+        P32_T(t6);
+#ifdef P32_STAMP
+        seg[0] += t4 - t0; seg[3] += t5 - t4; seg[4] += t6 - t5;
+#endif
+    };
+
+    uint4 sa[NST], sb[NST];
+    P32Geo g0, g1, g2;
+    geometry(tile, g0);
+#pragma unroll
+    for (int it = 0; it < NST; ++it) load_piece(g0, it, sa);
+    geometry(tile + t_stride, g1);
+#pragma unroll
+    for (int it = 0; it < NST; ++it) load_piece(g1, it, sb);
+#if !P32_BREG
+#pragma unroll
+    for (int it = 0; it < NWS; ++it)
+        if ((int)threadIdx.x + 256 * it < NWP) *reinterpret_cast<uint4*>(Bs + (threadIdx.x + 256 * it) * 8) = wst[it];
+#endif
+#pragma unroll
+    for (int it = 0; it < NST; ++it) store_piece(g0, it, sa, Xh);
+    __syncthreads();
+#ifdef P32_STAMP
+    P32_T(k1);
+#endif
+    for (; tile < t_end; tile += 2 * t_stride) {             // tile j of this workgroup's sequence: image j % 2, store set (j+1) % 2
+        one_tile(tile, g0, g1, sb, g2, sa, 0);               // computes g0, writes g1's halo (sb), requests g2 into sa
+        if (tile + t_stride >= t_end) break;                 // (uniform)
+        one_tile(tile + t_stride, g1, g2, sa, g0, sb, 1);    // computes g1, writes g2's halo (sa), requests the next g0 into sb
+        g1 = g0;                                             // rotate: the tile just requested is the one after the next
+        g0 = g2;
+        // after the swap: g0 = the tile to compute, whose halo is in image 0 -- its data travelled in sa; g1 = requested into sb
+    }
+#ifdef P32_STAMP
+    P32_T(k2);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        for (int i = 0; i < 6; ++i) p32_stamps[i] = seg[i];
+        p32_stamps[6] = k1 - k0;
+        p32_stamps[7] = k2 - k1;
+    }
+#endif
+}
+
 // First layer (ONE input channel -> 16 * NT): K = 27 taps, padded to a single 32-wide k-step whose A fragment is gathered
 // from a 1.2 KB scalar halo image (8 ds_read_u16 per lane and m-tile).  One MFMA per 16 voxels and n-tile: the kernel is a
 // pure HBM stream of its output (2 B in, 32 * NT B out per voxel).  wfrag = dycon_pack_bfrag(T = 27, Cin = 1).
@@ -1974,6 +2230,14 @@ extern "C" int dycon_conv_gemm_ex(const void* x, const void* wfrag, const float*
             else if (Cout == 16) conv_k3_c1_kernel<1><<<8 * per_xcd, 256, 0, stream>>>(xp, wp, bias, yp, B, Di, Hi, Wi, tz, ty, tx, nTiles, accumulate);
             else if (Cout == 32) conv_k3_c1_kernel<2><<<8 * per_xcd, 256, 0, stream>>>(xp, wp, bias, yp, B, Di, Hi, Wi, tz, ty, tx, nTiles, accumulate);
             else conv_k3_c1_kernel<4><<<8 * per_xcd, 256, 0, stream>>>(xp, wp, bias, yp, B, Di, Hi, Wi, tz, ty, tx, nTiles, accumulate);
+            DYCON_LAUNCH_CHECK();
+            return DYCON_OK;
+        }
+        // 32 -> 32 with several tiles per CU: persistent kernel, weights stationary in LDS (one workgroup per CU)
+        static const bool p32_on = env_ll("DYCON_P32", 1) != 0;
+        if (p32_on && Cin == 32 && Cout == 32 && !accumulate && nTiles >= 1024) {
+            const int per_xcd = min(cdiv(nTiles, 8), 32);
+            conv_k3_p32_kernel<<<8 * per_xcd, 256, 0, stream>>>((const bf16*)x, (const bf16*)wfrag, bias, (bf16*)y, B, Di, Hi, Wi, tz, ty, tx, nTiles);
             DYCON_LAUNCH_CHECK();
             return DYCON_OK;
         }

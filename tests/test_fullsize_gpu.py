@@ -53,7 +53,8 @@ FULL_CASES = [
     ("k3", 1, 16, (96, 96, 96)),      # conv_k3_c1 (persistent, first layer)
     ("k3", 16, 16, (96, 96, 96)),     # conv_k3_p16 (persistent, weight-stationary)
     ("k3", 16, 16, (112, 112, 96)),   # Pancreas geometry: partial tiles in H (112 = 14 x 8) ...
-    ("k3", 32, 32, (48, 48, 48)),     # conv_k3_lds <32,2,4>
+    ("k3", 32, 32, (48, 48, 48)),     # conv_k3_p32 (persistent, weights stationary in LDS)
+    ("k3", 32, 32, (46, 50, 44)),     # ... ragged tiles in all three directions
     ("k3", 64, 64, (24, 24, 24)),     # conv_k3_lds <32,4,2>
     ("k3", 32, 32, (56, 56, 48)),     # Pancreas level 2
     ("k3", 64, 64, (28, 28, 24)),     # Pancreas level 3 (28 = 3.5 x 8: ragged tiles)
