@@ -439,12 +439,13 @@ constexpr int CL_NV = CL_TZ * CL_TY * CL_TX;     // 256 voxels = 16 m-tiles
 #ifndef CL_BPREF
 #define CL_BPREF 0                                 // B fragments read one k-step ahead of their MFMAs
 #endif
-template <int CK, int NTB, int WM>
-__global__ __launch_bounds__(256, CL_LB2) void conv_k3_lds_kernel(const bf16* __restrict__ X, const bf16* __restrict__ Wf,
+template <int CK, int NTB, int WM, int NW = 4>     // NW waves per workgroup: 4, or 8 (two per SIMD) where the grid gives a CU one workgroup
+__global__ __launch_bounds__(64 * NW, NW == 4 ? CL_LB2 : 1) void conv_k3_lds_kernel(const bf16* __restrict__ X, const bf16* __restrict__ Wf,
                                                           const float* __restrict__ bias, bf16* __restrict__ Y, int B, int D, int H,
                                                           int W, int Cin, int Cout, int NT, int tilesZ, int tilesY, int tilesX,
                                                           int accumulate) {
-    constexpr int WN = 4 / WM;                 // waves along N
+    constexpr int NTHR = 64 * NW;
+    constexpr int WN = NW / WM;                // waves along N
     constexpr int MTW = 16 / WM;               // m-tiles per wave
     constexpr int NTW = NTB / WN;              // n-tiles per wave
     // LDS image of the halo tile, laid out so that every ds_read_b128 lane group (16 lanes = 8 x-neighbours of two y-rows,
@@ -491,9 +492,9 @@ __global__ __launch_bounds__(256, CL_LB2) void conv_k3_lds_kernel(const bf16* __
     constexpr int GRP = CK == 32 ? 9 : 7;                      // k-steps per B group
     constexpr int NG = NKS / GRP;                              // groups per chunk (3 or 2)
     constexpr int PPV = CK / 8;                                // 16-byte pieces per halo voxel
-    constexpr int NST = (CL_NH * PPV + 255) / 256;             // halo pieces per thread
+    constexpr int NST = (CL_NH * PPV + NTHR - 1) / NTHR;             // halo pieces per thread
     constexpr int BPIECES = GRP * NTB * 64;                    // 16-byte pieces of one B group (all n-tiles of the workgroup)
-    constexpr int NSB = (BPIECES + 255) / 256;                 // B pieces per thread
+    constexpr int NSB = (BPIECES + NTHR - 1) / NTHR;                 // B pieces per thread
 
     // Register-staged pipeline (issue early / write late): while the MFMAs of phase p run, the global loads of phase p+1
     // (next B group, and the next chunk's halo at a chunk boundary) are already in flight in registers; they are written to
@@ -502,7 +503,7 @@ __global__ __launch_bounds__(256, CL_LB2) void conv_k3_lds_kernel(const bf16* __
     auto load_halo = [&](int ch) {
 #pragma unroll
         for (int it = 0; it < NST; ++it) {
-            const int e = threadIdx.x + 256 * it;
+            const int e = threadIdx.x + NTHR * it;
             const int hv = e / PPV, pc = e % PPV;
             const int hx = hv % CL_HX, hy = (hv / CL_HX) % CL_HY, hz = hv / (CL_HX * CL_HY);
             const int z = z0 + hz - 1, y = y0 + hy - 1, x = x0 + hx - 1;
@@ -516,7 +517,7 @@ __global__ __launch_bounds__(256, CL_LB2) void conv_k3_lds_kernel(const bf16* __
     auto store_halo = [&]() {
 #pragma unroll
         for (int it = 0; it < NST; ++it) {
-            const int e = threadIdx.x + 256 * it;
+            const int e = threadIdx.x + NTHR * it;
             if (e < CL_NH * PPV) {
                 const int hv = e / PPV, pc = e % PPV;
                 const int hx = hv % CL_HX, hyz = hv / CL_HX;
@@ -528,7 +529,7 @@ __global__ __launch_bounds__(256, CL_LB2) void conv_k3_lds_kernel(const bf16* __
     auto load_b = [&](int ch, int g) {
 #pragma unroll
         for (int it = 0; it < NSB; ++it) {
-            const int e = threadIdx.x + 256 * it;          // piece (u, j, lane)
+            const int e = threadIdx.x + NTHR * it;          // piece (u, j, lane)
             const int ln = e & 63, j = (e >> 6) % NTB, u = e / (64 * NTB);
             const int ks = g * GRP + u;
             // CK = 32: flattened K = tap*Cin + channel in 32-chunks.  CK = 16: weights packed chunk-major (each 16-channel
@@ -542,7 +543,7 @@ __global__ __launch_bounds__(256, CL_LB2) void conv_k3_lds_kernel(const bf16* __
     auto store_b = [&]() {
 #pragma unroll
         for (int it = 0; it < NSB; ++it) {
-            const int e = threadIdx.x + 256 * it;
+            const int e = threadIdx.x + NTHR * it;
             if (e < BPIECES) *reinterpret_cast<uint4*>(Bs + e * 8) = stgB[it];
         }
     };
@@ -638,8 +639,8 @@ __global__ __launch_bounds__(256, CL_LB2) void conv_k3_lds_kernel(const bf16* __
     __syncthreads();
     constexpr int PPR = CBW / 8;                   // 16-byte pieces per voxel row
 #pragma unroll
-    for (int it = 0; it < CL_NV * PPR / 256; ++it) {
-        const int e = threadIdx.x + 256 * it;
+    for (int it = 0; it < CL_NV * PPR / NTHR; ++it) {
+        const int e = threadIdx.x + NTHR * it;
         const int v = e / PPR, pc = e % PPR;
         const int z = z0 + (v >> 6), y = y0 + ((v >> 3) & 7), x = x0 + (v & 7);
         if (z >= D || y >= H || x >= W) continue;
@@ -2247,7 +2248,11 @@ extern "C" int dycon_conv_gemm_ex(const void* x, const void* wfrag, const float*
         if (Cin == 16 || Cin == 48) {
             if (ntb == 1) DYCON_CL(16, 1, 4); else if (ntb == 2) DYCON_CL(16, 2, 4); else if (ntb == 3) DYCON_CL(16, 3, 4); else DYCON_CL(16, 4, 2);
         } else {
-            if (ntb == 1) DYCON_CL(32, 1, 4); else if (ntb == 2) DYCON_CL(32, 2, 4); else if (ntb == 3) DYCON_CL(32, 3, 4); else DYCON_CL(32, 4, 2);
+            static const bool w8_on = env_ll("DYCON_LDS_W8", 1) != 0;
+            if (ntb == 1) DYCON_CL(32, 1, 4); else if (ntb == 2) DYCON_CL(32, 2, 4); else if (ntb == 3) DYCON_CL(32, 3, 4);
+            else if (w8_on && (long long)nTiles * (NT / ntb) <= 256)     // at most one workgroup per CU: 8 waves, two per SIMD (a wave per SIMD is issue-bound)
+                conv_k3_lds_kernel<32, 4, 4, 8><<<grid, 512, 0, stream>>>((const bf16*)x, (const bf16*)wfrag, bias, (bf16*)y, B, Di, Hi, Wi, Cin, Cout, NT, tz, ty, tx, accumulate);
+            else DYCON_CL(32, 4, 2);
         }
 #undef DYCON_CL
         DYCON_LAUNCH_CHECK();
