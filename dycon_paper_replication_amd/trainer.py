@@ -71,6 +71,7 @@ class TrainConfig:
     overlap_features: bool = True       # feature branch (projection head, embeddings, FeCL forward + backward) on its own stream
     fuse_finish: bool = False           # small levels: split-K finish of a convolution done by the one-launch norm that follows (Engine.fuse_finish)
     norm_accumulators: bool = False     # two-launch norms through double-atomic accumulators (measured slower: DESIGN.md section 9)
+    ddp_force: bool = False             # run the data-parallel exchange with a ONE-rank process group as well (RCCL test on one GPU)
     replay: bool = True                 # after two eager steps of a given input signature, record the step's launch list once and
                                         # re-issue it with patched scalars (the step is host-enqueue-bound: see DyconTrainer.step);
                                         # single-process and data-parallel runs alike
@@ -83,6 +84,9 @@ class DyconTrainer:
         self.pg = process_group
         self.world = torch.distributed.get_world_size(process_group) if process_group is not None else 1
         self.rank = torch.distributed.get_rank(process_group) if process_group is not None else 0
+        # the data-parallel exchange (bucketed gradient all-reduce, 16 + 4-double loss exchange); ddp_force runs it with ONE rank too,
+        # where every collective is the identity (tests: the RCCL calls inside the recorded step, on the single GPU of a test box)
+        self.ddp = self.world > 1 or (cfg.ddp_force and process_group is not None)
         spec = param_spec(cfg.model, 1, 2, cfg.normalization)
         # parameters the loss never reaches keep grad=None in the reference and are skipped by
         # clip_grad_norm_/SGD (weight decay included): put them behind the SGD range of the arena
@@ -167,7 +171,7 @@ class DyconTrainer:
         # registration order, so a bucket is complete when its FIRST parameter's gradient has been enqueued; its all-reduce is
         # issued right then and overlaps the rest of the backward (xGMI ring: 4 x ~10 MB instead of one 39 MB transfer at the end).
         self.buckets = []
-        if self.world > 1:
+        if self.ddp:
             nb = 4
             heads = [k for k in order if offs[k] < self.n_sgd and len(spec[k]) == 5]   # conv weights: notified by the backward
             target = self.n_sgd / nb
@@ -381,7 +385,7 @@ class DyconTrainer:
         self._mark("student_fwd_end")
         # ---- losses (:308-357)
         world = self.world
-        glob = world > 1 and c.global_batch_losses
+        glob = self.ddp and c.global_batch_losses
         sums = ops.seg_losses_fwd(s_logits, t_logits, label, LB, beta, fast=self._fast_math)
         fctx = (lambda: ops.on_stream(self.feat)) if self.feat is not None else contextlib.nullcontext
         with fctx():
@@ -431,7 +435,7 @@ class DyconTrainer:
         self.s_eng.backward(g_logits, g_feat)            # head entries replay on self.feat, joins at the bottleneck gradient
 
         # ---- all-reduce, clip, SGD, EMA (:368-372)
-        if world > 1:      # bucketed all-reduces were issued during the backward (see __init__); wait for them here
+        if self.ddp:       # bucketed all-reduces were issued during the backward (see __init__); wait for them here
             def join():
                 assert len(self._pending) == len(self.buckets), "a gradient bucket was never triggered"
                 for h in self._pending:

@@ -6,7 +6,10 @@ into the SGD kernel.
 * u_weight = 0.5 (FeCL + UnCL ON, the default): against oracle.step.ddp_train_step, the CPU emulation in which every rank forwards
   its own shard (per-rank BatchNorm statistics in the projection head, as the reference's DataParallel replicas) and the 16 + 4
   accumulators are summed over ranks -- exercises fecl_finalize(rows = B*world*N) and the x world cross-branch gradient.
-* replay == eager under a process group (the recorded step contains the collectives)."""
+* replay == eager under a process group (the recorded step contains the collectives).
+* RCCL itself (backend "nccl"), with the ONE rank a single-GPU box allows: TrainConfig.ddp_force runs the whole exchange -- bucketed
+  async all-reduces issued from inside the backward, the fp64 accumulator exchange, the joins -- through RCCL, eager and replayed;
+  every collective is then the identity, so the run must reproduce the plain single-GPU run."""
 import os
 import tempfile
 
@@ -143,3 +146,45 @@ def test_two_rank_replay_equals_eager():
     np.testing.assert_allclose(got[True][0], got[False][0], rtol=1e-5, atol=1e-6)
     for a, b in zip(got[True][1:], got[False][1:]):
         assert float((a - b).abs().max()) <= 1e-6 * float(b.abs().max())
+
+
+def _rccl_worker(rank, init_file, out_file):
+    import torch.distributed as dist
+    from dycon_paper_replication_amd.synthetic import make_batch
+    from dycon_paper_replication_amd.trainer import DyconTrainer, TrainConfig
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", init_method=f"file://{init_file}", rank=0, world_size=1)
+    batches = [make_batch(700 + i, 4, (32, 32, 32)) for i in range(7)]
+    res = {}
+    for tag, kw, pg in (("plain", {}, None), ("rccl_eager", dict(ddp_force=True, replay=False), dist.group.WORLD),
+                        ("rccl_replay", dict(ddp_force=True, replay=True), dist.group.WORLD)):
+        tr = DyconTrainer(TrainConfig(model="vnet", labeled_bs=2, batch_size=4, dtype=torch.bfloat16, seed=5, base_lr=0.01, **kw), DEV,
+                          process_group=pg)
+        assert (len(tr.buckets) >= 2) == (pg is not None)
+        losses = []
+        for v, l, _ in batches:
+            out = tr.step(v.to(DEV), l.to(DEV))
+            losses.append([float(out[k]) for k in KEYS])
+        if tag == "rccl_replay":
+            assert tr._rp is not None
+        res[tag] = (np.array(losses), tr.flat_p.cpu(), tr.flat_t.cpu())
+    torch.cuda.synchronize()
+    torch.save(res, out_file)
+    dist.destroy_process_group()
+
+
+def test_rccl_one_rank_exchange_equals_plain_step():
+    import torch.multiprocessing as mp
+    with tempfile.TemporaryDirectory() as d:
+        init_file, out_file = os.path.join(d, "init"), os.path.join(d, "out.pt")
+        mp.spawn(_rccl_worker, args=(init_file, out_file), nprocs=1, join=True)
+        res = torch.load(out_file, weights_only=False)
+    ref = res["plain"]
+    for tag in ("rccl_eager", "rccl_replay"):
+        got = res[tag]
+        # same kernels, same order; only the FeCL / voxel-loss scalars are finalised by the exchange path's kernels
+        np.testing.assert_allclose(got[0], ref[0], rtol=2e-5, atol=1e-6, err_msg=tag)
+        for a, b, what in ((got[1], ref[1], "student"), (got[2], ref[2], "teacher")):
+            err = float((a - b).abs().max())
+            assert err <= 1e-5 * float(b.abs().max()), (tag, what, err)
+    assert torch.equal(res["rccl_eager"][1], res["rccl_replay"][1])
