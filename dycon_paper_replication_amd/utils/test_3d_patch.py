@@ -128,22 +128,101 @@ def calculate_metric_percase(pred, gt):
     return dice, jc, float(np.percentile(np.hstack((hd1, hd2)), 95)), float(hd1.mean())
 
 
-def test_all_case(model, cases, num_classes, patch_size=(96, 96, 64), stride_xy=16, stride_z=4, batch_size=4, metric_detail=0):
-    """cases: iterable of (image, label) arrays, or of h5 paths with 'image' / 'label' datasets (needs h5py).
-    Returns the mean (dice, jaccard, hd95, asd) over the cases (code/utils/test_3d_patch.py:251-291)."""
+def getLargestCC(segmentation):
+    """Largest connected component of a label map (code/utils/test_3d_patch.py:19-26; skimage.measure.label's default full
+    connectivity -- 26 neighbours in 3-D -- on scipy.ndimage, skimage is not vendored by the reference).  An empty map is returned
+    unchanged.  The `nms` option of the test_all_case family."""
+    from scipy import ndimage
+    seg = np.asarray(segmentation)
+    labels, n = ndimage.label(seg, structure=np.ones((3,) * seg.ndim, dtype=bool))
+    if n == 0:
+        return segmentation
+    return labels == np.argmax(np.bincount(labels.flat)[1:]) + 1
+
+
+def _read_case(case, label_key):
+    if isinstance(case, (str, bytes)):
+        import h5py   # not available in this image; present where the datasets are
+        with h5py.File(case, "r") as f:
+            return f["image"][:], f[label_key][:]
+    return case
+
+
+def test_all_case(model, cases, num_classes, patch_size=(96, 96, 64), stride_xy=16, stride_z=4, batch_size=4, metric_detail=0,
+                  nms=0, preproc_fn=None, test_save_path=None, label_key="label"):
+    """cases: iterable of (image, label) arrays, or of h5 paths with 'image' / `label_key` datasets (needs h5py).
+    Returns the mean (dice, jaccard, hd95, asd) over the cases; nms keeps the largest connected component of each prediction,
+    preproc_fn is applied to the image first, test_save_path receives `../performance.txt` (code/utils/test_3d_patch.py:251-291)."""
     total = np.zeros(4)
     n = 0
     for case in cases:
-        if isinstance(case, (str, bytes)):
-            import h5py   # not available in this image; present where the datasets are
-            with h5py.File(case, "r") as f:
-                image, label = f["image"][:], f["label"][:]
-        else:
-            image, label = case
+        image, label = _read_case(case, label_key)
+        if preproc_fn is not None:
+            image = preproc_fn(image)
         pred, _ = test_single_case(model, image, stride_xy, stride_z, patch_size, num_classes=num_classes, batch_size=batch_size)
+        if nms:
+            pred = getLargestCC(pred)
         m = (0.0, 0.0, 0.0, 0.0) if pred.sum() == 0 else calculate_metric_percase(pred, np.asarray(label))
         if metric_detail:
             print("%02d,\t%.5f, %.5f, %.5f, %.5f" % ((n,) + tuple(m)))
         total += np.asarray(m)
         n += 1
+    avg = total / max(n, 1)
+    if test_save_path is not None:
+        with open(test_save_path + "../performance.txt", "w") as f:
+            f.writelines("average metric is {} \n".format(avg))
+    return avg
+
+
+def _case_list(root_path, list_name, pattern):
+    import os
+    with open(os.path.join(root_path, list_name), "r") as f:
+        return [pattern.format(root=root_path, case=line.strip()) for line in f if line.strip()]
+
+
+def _mean_dice(model, cases, num_classes, patch_size, stride_xy, stride_z, label_key):
+    """validation during training: mean Dice of the sliding-window predictions (the var_all_case_* family, :52-74, :120-141, :188-209)"""
+    total, n = 0.0, 0
+    for case in cases:
+        image, label = _read_case(case, label_key)
+        pred, _ = test_single_case(model, image, stride_xy, stride_z, patch_size, num_classes=num_classes)
+        if pred.sum() != 0:
+            n_p, n_g, n_i = overlap_counts(pred, np.asarray(label))
+            total += 2.0 * n_i / float(n_p + n_g)
+        n += 1
     return total / max(n, 1)
+
+
+# per-dataset wrappers with the reference's names, defaults and on-disk layouts
+def var_all_case_BraTS19(model, root_path, num_classes, patch_size=(96, 96, 64), stride_xy=16, stride_z=4):
+    return _mean_dice(model, _case_list(root_path, "val.txt", "{root}/data/{case}.h5"), num_classes, patch_size, stride_xy, stride_z, "label")
+
+
+def var_all_case_Pancreas(model, root_path, num_classes, patch_size=(112, 112, 80), stride_xy=18, stride_z=4):
+    return _mean_dice(model, _case_list(root_path, "test.list", "{root}/Pancreas_data/{case}"), num_classes, patch_size, stride_xy, stride_z, "label")
+
+
+def var_all_case_ISLES22(root_path, model, num_classes, device=None, patch_size=(96, 96, 64), stride_xy=16, stride_z=4):
+    return _mean_dice(model, _case_list(root_path, "val.list", "{root}/{case}.h5"), num_classes, patch_size, stride_xy, stride_z, "mask")
+
+
+def test_all_case_BraTS19(model, image_list, num_classes, patch_size=(96, 96, 64), stride_xy=16, stride_z=4, save_result=True,
+                          test_save_path=None, preproc_fn=None, metric_detail=0, nms=0):
+    return test_all_case(model, image_list, num_classes, patch_size, stride_xy, stride_z, metric_detail=metric_detail, nms=nms,
+                         preproc_fn=preproc_fn, test_save_path=test_save_path)
+
+
+def test_all_case_Pancreas(model, image_list, num_classes, device=None, patch_size=(96, 96, 64), stride_xy=16, stride_z=4,
+                           save_result=True, test_save_path=None, preproc_fn=None, metric_detail=0, nms=0):
+    return test_all_case(model, image_list, num_classes, patch_size, stride_xy, stride_z, metric_detail=metric_detail, nms=nms,
+                         preproc_fn=preproc_fn, test_save_path=test_save_path)
+
+
+def test_all_case_ISLES22(model, image_list, num_classes, patch_size=(96, 96, 64), stride_xy=16, stride_z=4, save_result=True,
+                          test_save_path=None, preproc_fn=None, metric_detail=0, nms=0):
+    return test_all_case(model, image_list, num_classes, patch_size, stride_xy, stride_z, metric_detail=metric_detail, nms=nms,
+                         preproc_fn=preproc_fn, test_save_path=test_save_path, label_key="mask")
+
+
+for _f in (test_all_case, test_all_case_BraTS19, test_all_case_Pancreas, test_all_case_ISLES22):
+    _f.__test__ = False        # reference names, not pytest cases

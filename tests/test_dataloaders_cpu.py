@@ -55,3 +55,50 @@ def test_sagittal_to_axial():
     import pytest
     with pytest.raises(ValueError):
         D.SagittalToAxial()({"image": img, "label": lab[:5]})
+
+
+def test_pancreas_isles_transforms_and_samplers(tmp_path):
+    """the two other loader modules of the reference (code/dataloaders/pancreas.py, isles22.py): shared transforms re-exported,
+    CreateOnehotLabel / ToTensor with 'onehot_label', RandomRot, ThreeStreamBatchSampler, list-file handling of the datasets"""
+    from dycon_paper_replication_amd.dataloaders import isles22 as I
+    from dycon_paper_replication_amd.dataloaders import pancreas as P
+    assert P.RandomCrop is D.RandomCrop and I.RandomRotFlip is D.RandomRotFlip and I.TwoStreamBatchSampler is D.TwoStreamBatchSampler
+    rng = np.random.default_rng(2)
+    img = rng.standard_normal((10, 9, 8))
+    lab = (rng.random((10, 9, 8)) > 0.7).astype(np.uint8)
+    s = P.CreateOnehotLabel(2)({"image": img, "label": lab})
+    assert s["onehot_label"].shape == (2, 10, 9, 8) and s["onehot_label"].dtype == np.float32
+    np.testing.assert_array_equal(s["onehot_label"][1], lab.astype(np.float32))
+    np.testing.assert_array_equal(s["onehot_label"].sum(0), np.ones_like(lab, dtype=np.float32))
+    t = P.ToTensor()(s)
+    assert t["image"].shape == (1, 10, 9, 8) and t["image"].dtype == torch.float32
+    assert t["label"].dtype == torch.int64 and t["onehot_label"].dtype == torch.int64
+    st = I.CreateOnehotLabel(2)({"image": torch.from_numpy(img), "label": torch.from_numpy(lab)})
+    np.testing.assert_array_equal(st["onehot_label"].numpy(), s["onehot_label"])
+    # RandomRot: angle from np.random.randint(-20, 20), nearest neighbour, shape kept; angle 0 is the identity
+    from scipy import ndimage
+    np.random.seed(11)
+    angle = np.random.randint(-20, 20)
+    np.random.seed(11)
+    r = I.RandomRot()({"image": img, "label": lab})
+    np.testing.assert_array_equal(r["label"], ndimage.rotate(lab, angle, order=0, reshape=False))
+    assert r["image"].shape == img.shape and set(np.unique(r["label"])) <= {0, 1}
+    # ThreeStreamBatchSampler: primary + secondary + primary from ONE primary permutation, two groups per batch
+    np.random.seed(3)
+    batches = list(I.ThreeStreamBatchSampler(list(range(10)), list(range(10, 40)), batch_size=4, secondary_batch_size=2))
+    assert len(batches) == 2                      # 10 primaries: two batches of 2 + 2, the last pair of groups is incomplete
+    flat_primary = [i for b in batches for i in b[:2] + b[4:]]
+    assert all(i < 10 for i in flat_primary) and len(set(flat_primary)) == 8
+    assert all(len(b) == 6 and all(i >= 10 for i in b[2:4]) for b in batches)
+    # dataset list handling (no h5py needed until a sample is read)
+    (tmp_path / "train.list").write_text("case_a.h5\ncase_b.h5\ncase_c.h5\n")
+    (tmp_path / "test.list").write_text("case_z.h5\n")
+    ds = P.Pancreas(str(tmp_path), split="train", num=2)
+    assert len(ds) == 2 and ds.image_list == ["case_a.h5", "case_b.h5"]
+    assert len(P.Pancreas(str(tmp_path), split="val")) == 1
+    (tmp_path / "val.list").write_text("s1\ns2\n\n")
+    (tmp_path / "s1.h5").write_bytes(b"")
+    assert I.ISLESDataset(str(tmp_path), split="val").sample_list == ["s1.h5"]      # listed cases without a file are skipped
+    import pytest
+    with pytest.raises(FileNotFoundError):
+        I.ISLESDataset(str(tmp_path), split="nope")

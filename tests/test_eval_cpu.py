@@ -53,3 +53,18 @@ def test_window_enumeration_matches_host_mirror():
             assert x + patch[0] <= shape[0] and y + patch[1] <= shape[1] and z + patch[2] <= shape[2]
             cover[x:x + patch[0], y:y + patch[1], z:z + patch[2]] += 1
         assert cover.min() >= 1
+
+
+def test_largest_connected_component_known_answers():
+    """the evaluator's `nms` option (code/utils/test_3d_patch.py:19-26): skimage's default FULL connectivity (26 neighbours)"""
+    from dycon_paper_replication_amd.utils.test_3d_patch import getLargestCC
+    seg = np.zeros((12, 12, 12), np.int64)
+    seg[1:4, 1:4, 1:4] = 1                       # 27 voxels
+    seg[4, 4, 4] = 1                             # touches the cube only through a corner: same component under 26-connectivity
+    seg[8:10, 8:10, 8:11] = 1                    # 12 voxels, separate
+    out = getLargestCC(seg)
+    assert out.dtype == bool and out.sum() == 28 and out[4, 4, 4] and not out[8, 8, 8]
+    empty = np.zeros((4, 4, 4), np.int64)
+    assert getLargestCC(empty) is empty          # no component: returned unchanged
+    two = np.zeros((6, 6, 6), np.int64); two[0, 0, 0] = 1; two[3:5, 3:5, 3:5] = 1
+    assert getLargestCC(two).sum() == 8

@@ -105,3 +105,63 @@ def test_train_time_metrics():
     m.close()
     assert got["hd95"] is not None and got["hd95"][1] == pytest.approx(float(np.mean(hd)))
     np.testing.assert_allclose(got["dice"].cpu().numpy(), ref_dice, rtol=1e-6)
+
+
+def test_all_case_nms_and_dataset_wrappers(tmp_path):
+    """the `nms` (largest connected component) option and the per-dataset wrappers of the reference's evaluator
+    (code/utils/test_3d_patch.py:76-118,211-249): a 'network' of two blobs, the smaller one removed by nms"""
+    shape = (40, 40, 32)
+    big, small = _blob(shape, (14, 14, 14), 7), _blob(shape, (32, 32, 24), 3)
+    image = (big | small).astype(np.float32) * 4.0 - 2.0          # logit +2 inside the blobs, -2 outside
+
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.anchor = torch.nn.Parameter(torch.zeros(1))     # test_single_case takes the device from the parameters
+
+        def forward(self, x):
+            return None, torch.cat([-x, x], 1)
+
+    net = Net().cuda()
+    (tmp_path / "pred").mkdir()                # the reference's scripts create test_save_path before evaluating
+    m_all = T3.test_all_case(net, [(image, big.astype(np.uint8))], 2, patch_size=(32, 32, 16), stride_xy=8, stride_z=8)
+    m_nms = T3.test_all_case_BraTS19(net, [(image, big.astype(np.uint8))], 2, patch_size=(32, 32, 16), stride_xy=8, stride_z=8,
+                                     nms=1, test_save_path=str(tmp_path) + "/pred/")
+    assert m_nms[0] == pytest.approx(1.0) and m_nms[1] == pytest.approx(1.0) and m_nms[2] == 0.0
+    exp_dice = 2.0 * big.sum() / (2 * big.sum() + small.sum())
+    assert m_all[0] == pytest.approx(exp_dice, rel=1e-6) and m_all[2] > 10.0      # the far blob dominates HD95 without nms
+    assert (tmp_path / "performance.txt").read_text().startswith("average metric is")
+    m_isles = T3.test_all_case_ISLES22(net, [(image, (big | small).astype(np.float64))], 2, patch_size=(32, 32, 16), stride_xy=8, stride_z=8)
+    assert m_isles[0] == pytest.approx(1.0)
+    m_pre = T3.test_all_case_Pancreas(net, [(-image, big.astype(np.uint8))], 2, patch_size=(32, 32, 16), stride_xy=8, stride_z=8,
+                                      preproc_fn=lambda a: -a, nms=1)
+    assert m_pre[0] == pytest.approx(1.0)
+
+
+def test_device_side_transforms_match_host():
+    """the augmentation transforms on CUDA tensors (a volume cache in HBM) against the numpy path, same np.random stream"""
+    from dycon_paper_replication_amd.dataloaders import brats19 as D
+    from dycon_paper_replication_amd.dataloaders import pancreas as P
+    rng = np.random.default_rng(0)
+    img = rng.standard_normal((72, 60, 50)).astype(np.float32)
+    lab = (rng.random((72, 60, 50)) > 0.8).astype(np.uint8)
+    dev = {"image": torch.from_numpy(img).cuda(), "label": torch.from_numpy(lab).cuda()}
+    pipe = [D.SagittalToAxial(), D.RandomCrop((48, 48, 32)), D.RandomRotFlip(), D.RandomNoise(), P.CreateOnehotLabel(2), P.ToTensor()]
+    np.random.seed(21)
+    a = {"image": img, "label": lab}
+    for tf in pipe:
+        a = tf(a)
+    np.random.seed(21)
+    b = dev
+    for tf in pipe:
+        b = tf(b)
+    assert b["image"].is_cuda and b["label"].is_cuda and b["onehot_label"].is_cuda
+    np.testing.assert_allclose(b["image"].cpu().numpy(), a["image"].numpy(), rtol=0, atol=1e-6)
+    np.testing.assert_array_equal(b["label"].cpu().numpy(), a["label"].numpy())
+    np.testing.assert_array_equal(b["onehot_label"].cpu().numpy(), a["onehot_label"].numpy())
+    # pad path: crop larger than the volume in one direction
+    np.random.seed(4)
+    c = D.RandomCrop((48, 64, 32))({"image": img, "label": lab})
+    np.random.seed(4)
+    d = D.RandomCrop((48, 64, 32))(dev)
+    np.testing.assert_array_equal(d["image"].cpu().numpy(), c["image"])
