@@ -231,21 +231,47 @@ __global__ __launch_bounds__(256) void norm_apply_kernel(const T* __restrict__ X
     __syncthreads();
     const long long total = V * C / VN;
     const long long base = (long long)n * V * C;
+    // channel of a thread's first element: once per thread (a 64-bit modulo per 16-byte vector used to cost as many vector
+    // instructions as the normalisation itself); it advances by the grid stride modulo C -- zero whenever C divides 256 * VN * grid
+    int c0 = (int)((((long long)blockIdx.x * 256 + threadIdx.x) * VN) % C);
+    const int cstep = (int)(((long long)gridDim.x * 256 * VN) % C);
+    if (cstep == 0) {                          // (uniform) the thread's channels never change: scale / shift / dropout factor in registers
+        float sc[VN], sh[VN], dr[VN];
+#pragma unroll
+        for (int k = 0; k < VN; ++k) { sc[k] = ss[c0 + k]; sh[k] = ss[C + c0 + k]; dr[k] = ss[2 * C + c0 + k]; }
+        for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+            const long long e = i * VN;
+            Vec16<T> x = ld16(X + base + e), s;
+            if (skip) s = ld16(skip + base + e);
+            Vec16<T> y;
+#pragma unroll
+            for (int k = 0; k < VN; ++k) {
+                float v = x.get(k) * sc[k] + sh[k];
+                if (relu) v = v < 0.f ? 0.f : v;   // NaN-propagating, like torch.relu (fmaxf would swallow a NaN)
+                v *= dr[k];                        // fused nn.Dropout3d: keep[n,c] / (1-p)   (1 when absent)
+                if (skip) v += s.get(k);
+                y.set(k, v);
+            }
+            st16(Y + base + e, y);
+        }
+        return;
+    }
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
         const long long e = i * VN;
-        const int c0 = (int)(e % C);
         Vec16<T> x = ld16(X + base + e), s;
         if (skip) s = ld16(skip + base + e);
         Vec16<T> y;
 #pragma unroll
         for (int k = 0; k < VN; ++k) {
             float v = x.get(k) * ss[c0 + k] + ss[C + c0 + k];
-            if (relu) v = v < 0.f ? 0.f : v;   // NaN-propagating, like torch.relu (fmaxf would swallow a NaN)
-            v *= ss[2 * C + c0 + k];           // fused nn.Dropout3d: keep[n,c] / (1-p)   (1 when absent)
+            if (relu) v = v < 0.f ? 0.f : v;
+            v *= ss[2 * C + c0 + k];
             if (skip) v += s.get(k);
             y.set(k, v);
         }
         st16(Y + base + e, y);
+        c0 += cstep;
+        if (c0 >= C) c0 -= C;
     }
 }
 
@@ -297,9 +323,33 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(const T* __restrict
     __syncthreads();
     const long long total = V * C / VN;
     const long long base = (long long)n * V * C;
+    int c0 = (int)((((long long)blockIdx.x * 256 + threadIdx.x) * VN) % C);     // see norm_apply_kernel
+    const int cstep = (int)(((long long)gridDim.x * 256 * VN) % C);
+    if (cstep == 0 && !from_y) {               // (uniform) per-channel constants in registers, folded: gx = g*p + (x*q + r)
+        float mu[VN], rs[VN], gmv[VN], btv[VN], pa[VN], pb[VN], dr[VN];
+#pragma unroll
+        for (int k = 0; k < VN; ++k) {
+            const int c = c0 + k;
+            mu[k] = ss[c]; rs[k] = ss[C + c]; gmv[k] = ss[2 * C + c]; btv[k] = ss[3 * C + c];
+            pa[k] = ss[4 * C + c]; pb[k] = ss[5 * C + c]; dr[k] = ss[6 * C + c];
+        }
+        for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+            const long long e = i * VN;
+            const Vec16<T> s = ld16(S + base + e), gv = ld16(GY + base + e);
+            Vec16<T> o;
+#pragma unroll
+            for (int k = 0; k < VN; ++k) {
+                const float xh = (s.get(k) - mu[k]) * rs[k];
+                float g = gv.get(k) * dr[k];
+                if (relu && !(gmv[k] * xh + btv[k] > 0.f)) g = 0.f;
+                o.set(k, rs[k] * (gmv[k] * g - (pa[k] + xh * pb[k])));
+            }
+            st16(GX + base + e, o);
+        }
+        return;
+    }
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
         const long long e = i * VN;
-        const int c0 = (int)(e % C);
         const Vec16<T> s = ld16(S + base + e), gv = ld16(GY + base + e);
         Vec16<T> o;
 #pragma unroll
@@ -318,6 +368,8 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(const T* __restrict
             o.set(k, rstd * (gm * g - (ss[4 * C + c] + xh * ss[5 * C + c])));
         }
         st16(GX + base + e, o);
+        c0 += cstep;
+        if (c0 >= C) c0 -= C;
     }
 }
 
