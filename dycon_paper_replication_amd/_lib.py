@@ -43,6 +43,10 @@ SIGNATURES = {
     "dycon_norm_bwd": (I, [P, I, P, P, I, I, L, I, I, P, P, P, I, P, P, P, P, Z, P]),
     "dycon_norm_bwd_ex": (I, [P, I, P, P, I, I, L, I, I, P, P, P, I, P, P, P, I, P, Z, P]),
     "dycon_norm_sum_dparams": (I, [P, I, I, P, P, P]),
+    "dycon_norm_head_workspace": (Z, [I, L]),
+    "dycon_norm_head_fwd": (I, [P, I, I, L, I, P, P, P, I, P, P, P, P, P]),
+    "dycon_norm_head_bwd": (I, [P, P, P, I, I, L, I, P, P, P, I, P, P, P, P, P, Z, P]),
+    "dycon_norm_head_dparams": (I, [P, I, L, P, P, P]),
     "dycon_norm_acc_doubles": (Z, [I, L, I]),
     "dycon_norm_fwd_acc": (I, [P, P, I, I, L, I, I, F, P, P, P, I, P, P, P, P, F, P, P]),
     "dycon_norm_bwd_acc": (I, [P, P, P, I, I, L, I, I, P, P, P, I, P, P, P, P, P, Z, P]),

@@ -761,6 +761,272 @@ extern "C" int dycon_norm_bwd_ex(const void* src, int from_y, const void* gy, vo
 }
 
 // ------------------------------------------------------------------------------------------------
+// The 2-class head fused into the LAST normalisation of the V-Net (block_nine: conv -> norm -> ReLU [-> Dropout3d] -> out_conv 1x1,
+// VNet.py:225-227).  At 96^3 the normalised 16-channel tensor y is the largest activation of the step and its only consumers are a
+// 16 -> 2 matrix product forward, the 2 -> 16 product that makes its gradient, and the 2 x 16 weight gradient.  So y and its
+// gradient are never materialised:
+//   forward : norm statistics (dycon_norm_stats), then ONE pass  x -> y (registers) -> logits          (was: apply + 1x1 head)
+//   backward: the two passes of the norm backward form  gy = g_logits . W  per voxel on the fly and the statistics pass also
+//             accumulates dW = sum g_logits (x) y and db = sum g_logits                      (was: + head dgrad + head wgrad)
+// Arithmetic per voxel is that of norm_apply_kernel / head_1x1_fwd_kernel / head_1x1_bwd_kernel, including the rounding of y and
+// gy to the storage type: the logits are the unfused path's bit for bit, gz to fp32 round-off; dW / db differ in summation order.
+// ------------------------------------------------------------------------------------------------
+constexpr int HC = 16, HK = 2;                      // channels in, logits out
+constexpr int HPART = HK * HC + HK;                 // per-chunk head partials: dW[k][c], db[k]
+
+template <typename T> __device__ __forceinline__ float round_to(float v) { T t; stf(&t, v); return ldf(&t); }
+
+template <typename T>
+__global__ __launch_bounds__(256) void norm_apply_head_kernel(const T* __restrict__ X, long long V, int G,
+                                                              const float* __restrict__ stats, const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta, int relu,
+                                                              const float* __restrict__ chan_scale, const float* __restrict__ W,
+                                                              const float* __restrict__ hb, float* __restrict__ L) {
+    constexpr int VN = Vec16<T>::N;
+    __shared__ float ss[3 * HC + HK * HC + HK];
+    const int n = blockIdx.y, cpg = HC / G;
+    if (threadIdx.x < HC) {
+        const int c = threadIdx.x, g = c / cpg;
+        const float mean = stats[((long long)n * G + g) * 2], rstd = stats[((long long)n * G + g) * 2 + 1];
+        const float gm = gamma ? gamma[c] : 1.f, bt = beta ? beta[c] : 0.f;
+        ss[c] = rstd * gm;
+        ss[HC + c] = bt - mean * rstd * gm;
+        ss[2 * HC + c] = chan_scale ? chan_scale[(long long)n * HC + c] : 1.f;
+    }
+    if (threadIdx.x < HK * HC) ss[3 * HC + threadIdx.x] = W[threadIdx.x];
+    if (threadIdx.x < HK) ss[3 * HC + HK * HC + threadIdx.x] = hb ? hb[threadIdx.x] : 0.f;
+    __syncthreads();
+    float sc[HC], sh[HC], dr[HC], w0[HC], w1[HC];
+#pragma unroll
+    for (int c = 0; c < HC; ++c) { sc[c] = ss[c]; sh[c] = ss[HC + c]; dr[c] = ss[2 * HC + c]; w0[c] = ss[3 * HC + c]; w1[c] = ss[4 * HC + c]; }
+    const float b0 = ss[3 * HC + HK * HC], b1 = ss[3 * HC + HK * HC + 1];
+    const T* xp = X + (long long)n * V * HC;
+    float2* lp = reinterpret_cast<float2*>(L) + (long long)n * V;
+    for (long long v = (long long)blockIdx.x * 256 + threadIdx.x; v < V; v += (long long)gridDim.x * 256) {
+        float o0 = b0, o1 = b1;
+#pragma unroll
+        for (int c0 = 0; c0 < HC; c0 += VN) {
+            const Vec16<T> x = ld16(xp + v * HC + c0);
+#pragma unroll
+            for (int k = 0; k < VN; ++k) {
+                const int c = c0 + k;
+                float y = x.get(k) * sc[c] + sh[c];
+                if (relu) y = y < 0.f ? 0.f : y;
+                y = round_to<T>(y * dr[c]);          // what norm_apply_kernel would have stored
+                o0 += y * w0[c];
+                o1 += y * w1[c];
+            }
+        }
+        lp[v] = make_float2(o0, o1);
+    }
+}
+
+// statistics pass of the backward: thread mapping, row order and summation order of norm_partial_kernel<T, 1>, with gy formed on the fly;
+// additionally the head's weight / bias gradient partials of the chunk (hpart[(n, chunk)][HPART])
+template <typename T>
+__global__ __launch_bounds__(256) void norm_head_partial_kernel(const T* __restrict__ S, const float* __restrict__ GL,
+                                                                float* __restrict__ part, float* __restrict__ hpart, long long V,
+                                                                int G, long long rows_per_chunk, const float* __restrict__ stats,
+                                                                const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                int relu, const float* __restrict__ chan_scale,
+                                                                const float* __restrict__ W) {
+    constexpr int VN = Vec16<T>::N;
+    constexpr int NGRP = HC / VN, RPI = 256 / NGRP;
+    __shared__ float sm[4][256][VN + 1];
+    __shared__ float sb[256][HK];
+    const int n = blockIdx.y, chunk = blockIdx.x;
+    const int cg = threadIdx.x % NGRP, rr = threadIdx.x / NGRP;
+    const long long v0 = chunk * rows_per_chunk, v1 = min(V, v0 + rows_per_chunk);
+    const int cpg = HC / G;
+    float a0[VN], a1[VN], d0[VN], d1[VN], e0 = 0.f, e1 = 0.f;
+    float mean[VN], rstd[VN], gm[VN], bt[VN], cs[VN], sc[VN], sh[VN], w0[VN], w1[VN];
+#pragma unroll
+    for (int k = 0; k < VN; ++k) {
+        const int c = cg * VN + k, g = c / cpg;
+        a0[k] = a1[k] = d0[k] = d1[k] = 0.f;
+        cs[k] = chan_scale ? chan_scale[(long long)n * HC + c] : 1.f;
+        mean[k] = stats[((long long)n * G + g) * 2];
+        rstd[k] = stats[((long long)n * G + g) * 2 + 1];
+        gm[k] = gamma ? gamma[c] : 1.f;
+        bt[k] = beta ? beta[c] : 0.f;
+        sc[k] = rstd[k] * gm[k];
+        sh[k] = bt[k] - mean[k] * rstd[k] * gm[k];
+        w0[k] = W[c];
+        w1[k] = W[HC + c];
+    }
+    const T* sp = S + ((long long)n * V) * HC + cg * VN;
+    const float2* gp = reinterpret_cast<const float2*>(GL) + (long long)n * V;
+    for (long long v = v0 + rr; v < v1; v += RPI) {
+        const Vec16<T> s = ld16(sp + v * HC);
+        const float2 gl = gp[v];
+#pragma unroll
+        for (int k = 0; k < VN; ++k) {
+            float gyv = 0.f;                         // head_1x1_bwd_kernel's order and rounding
+            gyv += gl.x * w0[k];
+            gyv += gl.y * w1[k];
+            float g = round_to<T>(gyv) * cs[k];
+            const float x = s.get(k);
+            const float xh = (x - mean[k]) * rstd[k];
+            if (relu && !(gm[k] * xh + bt[k] > 0.f)) g = 0.f;
+            a0[k] += g;
+            a1[k] += g * xh;
+            float y = x * sc[k] + sh[k];             // the forward's y (norm_apply_head_kernel)
+            if (relu) y = y < 0.f ? 0.f : y;
+            y = round_to<T>(y * cs[k]);
+            d0[k] += gl.x * y;
+            d1[k] += gl.y * y;
+        }
+        if (cg == 0) { e0 += gl.x; e1 += gl.y; }
+    }
+#pragma unroll
+    for (int k = 0; k < VN; ++k) {
+        sm[0][threadIdx.x][k] = a0[k]; sm[1][threadIdx.x][k] = a1[k];
+        sm[2][threadIdx.x][k] = d0[k]; sm[3][threadIdx.x][k] = d1[k];
+    }
+    sb[threadIdx.x][0] = e0; sb[threadIdx.x][1] = e1;
+    __syncthreads();
+    if (threadIdx.x < HC) {                          // {sum g, sum g*xhat} per channel, as norm_partial_kernel stores them
+        const int o = threadIdx.x, og = o / VN, ok = o % VN;
+        float s0 = 0.f, s1 = 0.f;
+        for (int q = 0; q < RPI; ++q) { s0 += sm[0][q * NGRP + og][ok]; s1 += sm[1][q * NGRP + og][ok]; }
+        float* d = part + ((((long long)n * gridDim.x + chunk) * HC) + o) * 2;
+        d[0] = s0;
+        d[1] = s1;
+    } else if (threadIdx.x >= 64 && threadIdx.x < 64 + HK * HC) {
+        const int j = threadIdx.x - 64, kk = j / HC, o = j % HC, og = o / VN, ok = o % VN;
+        float s0 = 0.f;
+        for (int q = 0; q < RPI; ++q) s0 += sm[2 + kk][q * NGRP + og][ok];
+        hpart[((long long)n * gridDim.x + chunk) * HPART + j] = s0;
+    } else if (threadIdx.x >= 128 && threadIdx.x < 128 + HK) {
+        const int kk = threadIdx.x - 128;
+        float s0 = 0.f;
+        for (int q = 0; q < 256; ++q) s0 += sb[q][kk];
+        hpart[((long long)n * gridDim.x + chunk) * HPART + HK * HC + kk] = s0;
+    }
+}
+
+// sums of the head partials over all (n, chunk): one workgroup per output (HPART of them)
+__global__ __launch_bounds__(256) void norm_head_finalize_kernel(const float* __restrict__ hpart, int items, float* __restrict__ dW,
+                                                                 float* __restrict__ db) {
+    const int j = blockIdx.x;
+    double s0 = 0.0, s1 = 0.0;
+    for (int e = threadIdx.x; e < items; e += 256) s0 += hpart[(long long)e * HPART + j];
+    block_sum2_double(s0, s1);
+    if (threadIdx.x == 0) {
+        if (j < HK * HC) { if (dW) dW[j] = (float)s0; }
+        else if (db) db[j - HK * HC] = (float)s0;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void norm_head_bwd_apply_kernel(const T* __restrict__ S, const float* __restrict__ GL,
+                                                                  T* __restrict__ GX, long long V, int G,
+                                                                  const float* __restrict__ stats, const float* __restrict__ gamma,
+                                                                  const float* __restrict__ beta, const float* __restrict__ ab,
+                                                                  int relu, const float* __restrict__ chan_scale,
+                                                                  const float* __restrict__ W) {
+    constexpr int VN = Vec16<T>::N;
+    constexpr int NGRP = HC / VN;
+    const int n = blockIdx.y, cpg = HC / G;
+    const float inv_cnt = 1.f / ((float)V * (float)cpg);
+    const long long total = V * NGRP;
+    // 256 * VN is a multiple of 16: a thread's channels never change
+    const int cg = threadIdx.x % NGRP;
+    float mu[VN], rs[VN], gmv[VN], btv[VN], pa[VN], pb[VN], dr[VN], w0[VN], w1[VN];
+#pragma unroll
+    for (int k = 0; k < VN; ++k) {
+        const int c = cg * VN + k, g = c / cpg;
+        mu[k] = stats[((long long)n * G + g) * 2];
+        rs[k] = stats[((long long)n * G + g) * 2 + 1];
+        gmv[k] = gamma ? gamma[c] : 1.f;
+        btv[k] = beta ? beta[c] : 0.f;
+        pa[k] = ab[((long long)n * G + g) * 2] * inv_cnt;
+        pb[k] = ab[((long long)n * G + g) * 2 + 1] * inv_cnt;
+        dr[k] = chan_scale ? chan_scale[(long long)n * HC + c] : 1.f;
+        w0[k] = W[c];
+        w1[k] = W[HC + c];
+    }
+    const long long base = (long long)n * V * HC;
+    const float2* gp = reinterpret_cast<const float2*>(GL) + (long long)n * V;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const Vec16<T> s = ld16(S + base + i * VN);
+        const float2 gl = gp[i / NGRP];
+        Vec16<T> o;
+#pragma unroll
+        for (int k = 0; k < VN; ++k) {
+            float gyv = 0.f;
+            gyv += gl.x * w0[k];
+            gyv += gl.y * w1[k];
+            float g = round_to<T>(gyv) * dr[k];
+            const float xh = (s.get(k) - mu[k]) * rs[k];
+            if (relu && !(gmv[k] * xh + btv[k] > 0.f)) g = 0.f;
+            o.set(k, rs[k] * (gmv[k] * g - (pa[k] + xh * pb[k])));
+        }
+        st16(GX + base + i * VN, o);
+    }
+}
+
+extern "C" size_t dycon_norm_head_workspace(int Nb, long long V) {
+    const NormPlan p = norm_plan(V);
+    return dycon_norm_workspace(Nb, V, HC) + (size_t)Nb * p.chunks * HPART * sizeof(float);
+}
+
+extern "C" int dycon_norm_head_fwd(const void* x, int dtype, int Nb, long long V, int G, const float* stats, const float* gamma,
+                                   const float* beta, int relu, const float* chan_scale, const float* head_w, const float* head_b,
+                                   float* logits, dycon_stream_t stream) {
+    DYCON_REQUIRE(x && stats && head_w && logits, "norm_head_fwd: null pointer");
+    if (int e = norm_check("norm_head_fwd", dtype, Nb, V, HC, G)) return e;
+    long long blocks = (V + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    dim3 grid((int)blocks, Nb);
+    DYCON_DISPATCH(dtype, {
+        norm_apply_head_kernel<T><<<grid, 256, 0, stream>>>((const T*)x, V, G, stats, gamma, beta, relu, chan_scale, head_w, head_b, logits);
+    });
+    DYCON_LAUNCH_CHECK();
+    return DYCON_OK;
+}
+
+extern "C" int dycon_norm_head_bwd(const void* x, const float* g_logits, void* gx, int dtype, int Nb, long long V, int G,
+                                   const float* stats, const float* gamma, const float* beta, int relu, const float* chan_scale,
+                                   const float* head_w, float* dgamma, float* dbeta, float* workspace, size_t ws_bytes,
+                                   dycon_stream_t stream) {
+    DYCON_REQUIRE(x && g_logits && gx && stats && head_w && workspace, "norm_head_bwd: null pointer");
+    if (int e = norm_check("norm_head_bwd", dtype, Nb, V, HC, G)) return e;
+    DYCON_REQUIRE(ws_bytes >= dycon_norm_head_workspace(Nb, V), "norm_head_bwd: workspace too small");
+    const NormPlan p = norm_plan(V);
+    float* ab = workspace + (size_t)Nb * p.chunks * HC * 2;
+    float* hpart = workspace + dycon_norm_workspace(Nb, V, HC) / sizeof(float);
+    dim3 grid(p.chunks, Nb);
+    DYCON_DISPATCH(dtype, {
+        norm_head_partial_kernel<T><<<grid, 256, 0, stream>>>((const T*)x, g_logits, workspace, hpart, V, G, p.rows_per_chunk, stats, gamma,
+                                                              beta, relu, chan_scale, head_w);
+    });
+    DYCON_LAUNCH_CHECK();
+    const int nfin = Nb * G + ((dgamma || dbeta) ? HC : 0);
+    norm_finalize_bwd_kernel<<<nfin, 256, 0, stream>>>(workspace, Nb, p.chunks, HC, G, gamma, ab, dgamma, dbeta);
+    DYCON_LAUNCH_CHECK();
+    DYCON_DISPATCH(dtype, {
+        dim3 grid2(apply_grid(V, HC, Vec16<T>::N), Nb);
+        norm_head_bwd_apply_kernel<T><<<grid2, 256, 0, stream>>>((const T*)x, g_logits, (T*)gx, V, G, stats, gamma, beta, ab, relu, chan_scale,
+                                                                 head_w);
+    });
+    DYCON_LAUNCH_CHECK();
+    return DYCON_OK;
+}
+
+// the head's weight / bias gradient from the partials dycon_norm_head_bwd left in its workspace (a tiny launch the caller may put on
+// another stream: nothing on the data-gradient chain depends on it)
+extern "C" int dycon_norm_head_dparams(const float* workspace, int Nb, long long V, float* d_head_w, float* d_head_b,
+                                       dycon_stream_t stream) {
+    DYCON_REQUIRE(workspace && (d_head_w || d_head_b), "norm_head_dparams: bad arguments");
+    const NormPlan p = norm_plan(V);
+    const float* hpart = workspace + dycon_norm_workspace(Nb, V, HC) / sizeof(float);
+    norm_head_finalize_kernel<<<HPART, 256, 0, stream>>>(hpart, Nb * p.chunks, d_head_w, d_head_b);
+    DYCON_LAUNCH_CHECK();
+    return DYCON_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
 // Accumulator forms: the caller provides `acc`, dycon_norm_acc_doubles() doubles that are ZERO on entry (a slice of an arena it
 // clears once per step; Nb x nslots x C x 2: the chunks of a sample are spread over nslots copies of its accumulators).
 // Shapes served by the one-launch kernels (dycon_norm_fwd_is_fused) ignore it; the others run statistics + apply as TWO launches

@@ -194,6 +194,7 @@ class Engine:
         # less, but measured SLOWER (5.8 -> 6.1 ms/step): the norm's workgroups own 8-16 channels of one sample, so they read the
         # fp32 slabs in 32-byte pieces at a C*4-byte stride where splitk_finish streams them fully coalesced.  Off by default.
         self.fuse_finish = False
+        self.fuse_head = True            # V-Net: the 2-class head inside the last normalisation's passes (_norm_head)
         self._deferred = {}
         self._pending_dparams = []
         self.tape = []
@@ -486,6 +487,55 @@ class Engine:
             self.tape.append(bwd)
         return y
 
+    def _norm_head(self, prefix, z, kind, head, training=True, chan_scale=None):
+        """block_nine's norm -> ReLU [-> Dropout3d] -> out_conv (VNet.py:225-227) as ONE pass over the pre-norm tensor, forward and
+        backward: the normalised 16-channel tensor (the largest activation of the step) and its gradient are never written
+        (csrc/norm.hip, dycon_norm_head_*).  Same logits as _norm + _conv('1x1') bit for bit, same data gradient to fp32 round-off."""
+        B, C = z.shape[0], z.shape[-1]
+        V = z.numel() // (B * C)
+        gamma = beta = rm = rv = None
+        if kind == "gn":
+            Nb, G = B, 16
+            gamma, beta = self.p[prefix + ".weight"], self.p[prefix + ".bias"]
+        elif kind == "in":
+            Nb, G = B, C
+        else:
+            Nb, G, V = 1, C, B * V
+            gamma, beta = self.p[prefix + ".weight"], self.p[prefix + ".bias"]
+            rm, rv = self.buf.get(prefix + ".running_mean"), self.buf.get(prefix + ".running_var")
+        hw, hb = self.p[head + ".weight"], self.p[head + ".bias"]
+        if kind == "bn" and not training:
+            stats = torch.stack([rm, torch.rsqrt(rv + 1e-5)], 1).reshape(-1).contiguous()
+        else:
+            upd = kind == "bn" and training and self.update_bn
+            stats = ops.norm_stats(z, Nb, V, C, G, 1e-5, rm if upd else None, rv if upd else None, 0.1)
+            if upd and prefix + ".num_batches_tracked" in self.buf:
+                nbt = self.buf[prefix + ".num_batches_tracked"]
+                ops.rec(lambda: nbt.add_(1))
+        logits = ops.norm_head_fwd(z, stats, Nb, V, G, hw, hb, gamma, beta, True, chan_scale)
+        if self.recording:
+            def bwd():
+                gl = self._take(logits)
+                dg = self.g[prefix + ".weight"] if gamma is not None else None
+                db = self.g[prefix + ".bias"] if beta is not None else None
+                gz, pend = ops.norm_head_bwd(z, gl, stats, Nb, V, G, hw, gamma, beta, True, dg, db, chan_scale)
+                gw, gb = self.g[head + ".weight"], self.g[head + ".bias"]
+                if self.wgrad_stream is not None:      # the head's 2 x 16 weight gradient: a sum of per-chunk partials, off the chain
+                    ev, cs, ws_ = torch.cuda.Event(), ops.cur_stream(), self.wgrad_stream
+                    ops.rec(lambda: (ev.record(cs), ws_.wait_event(ev)))
+                    with ops.on_stream(self.wgrad_stream, light=True):
+                        ops.norm_head_dparams(pend, gw, gb)
+                    pend[0].record_stream(self.wgrad_stream)
+                else:
+                    ops.norm_head_dparams(pend, gw, gb)
+                if self.on_param_grads is not None:
+                    self.on_param_grads(head + ".weight")
+                    if gamma is not None:
+                        self.on_param_grads(prefix + ".weight")
+                self._give(z, gz)
+            self.tape.append(bwd)
+        return logits
+
     # ---------------------------------------------------------------- dropout sites
     def _channel_scale(self, B, C, key, p, site, device):
         """nn.Dropout3d(p) as a per-(sample, channel) factor keep/(1-p); applied INSIDE the preceding norm kernel."""
@@ -589,8 +639,13 @@ class Engine:
         u = up("block_six_up", block("block_six", u, 3), x3)
         u = up("block_seven_up", block("block_seven", u, 3), x2)
         u = up("block_eight_up", block("block_eight", u, 2), x1)
-        x9 = block("block_nine", u, 1, drop=("drop9", 1))                            # + Dropout3d, VNet.py:225-226
-        logits = self._conv("out_conv", x9, "1x1", out_dtype=torch.float32)
+        if self.fuse_head and nk != "none":          # block_nine's norm + ReLU + Dropout3d + out_conv in one pass (see _norm_head)
+            z9 = self._conv("block_nine.conv.0", u, "k3", norm_groups=ngroups(u, "block_nine.conv.0"))
+            cs9 = self._channel_scale(z9.shape[0], z9.shape[-1], "drop9", 0.5, 1, z9.device)
+            logits = self._norm_head("block_nine.conv.1", z9, nk, "out_conv", training=training, chan_scale=cs9)
+        else:
+            x9 = block("block_nine", u, 1, drop=("drop9", 1))                        # + Dropout3d, VNet.py:225-226
+            logits = self._conv("out_conv", x9, "1x1", out_dtype=torch.float32)
         feats = self._head_branch(x5, x5_ready, training)
         return logits, feats, None
 

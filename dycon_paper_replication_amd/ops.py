@@ -376,6 +376,30 @@ def norm_bwd(src, from_y, gy, stats, Nb, V, C, G, gamma=None, beta=None, relu=Tr
     return out
 
 
+def norm_head_fwd(x, stats, Nb, V, G, head_w, head_b, gamma=None, beta=None, relu=True, chan_scale=None):
+    """the 2-class head fused into the last normalisation (16 channels): logits (Nb, D, H, W, 2) fp32 straight from the pre-norm tensor"""
+    logits = torch.empty(x.shape[:-1] + (2,), dtype=torch.float32, device=x.device)
+    with _Region("norm_fwd", x.numel() * _es(x) + logits.numel() * 4, 8 * x.numel()):
+        call("dycon_norm_head_fwd", _p(x), dt(x), Nb, V, G, _p(stats), _p(gamma), _p(beta), int(relu), _p(chan_scale), _p(head_w),
+             _p(head_b), _p(logits), _s())
+    return logits
+
+
+def norm_head_bwd(x, g_logits, stats, Nb, V, G, head_w, gamma=None, beta=None, relu=True, dgamma=None, dbeta=None, chan_scale=None):
+    """returns (gx, pending): pending -> norm_head_dparams(pending, d_head_w, d_head_b) on any stream"""
+    gx = torch.empty_like(x)
+    ws = _ws(query("dycon_norm_head_workspace", Nb, V), x)
+    with _Region("norm_bwd", x.numel() * _es(x) * 3 + g_logits.numel() * 8, 14 * x.numel()):
+        call("dycon_norm_head_bwd", _p(x), _p(g_logits), _p(gx), dt(x), Nb, V, G, _p(stats), _p(gamma), _p(beta), int(relu),
+             _p(chan_scale), _p(head_w), _p(dgamma), _p(dbeta), _p(ws), ws.numel() * 4, _s())
+    return gx, (ws, Nb, V)
+
+
+def norm_head_dparams(pending, d_head_w, d_head_b):
+    ws, Nb, V = pending
+    call("dycon_norm_head_dparams", _p(ws), Nb, V, _p(d_head_w), _p(d_head_b), _s())
+
+
 def norm_sum_dparams(pending):
     """finish a deferred norm_bwd (ops.norm_bwd(..., defer_dparams=True)) on the CURRENT launch stream"""
     ws, Nb, C, dgamma, dbeta = pending

@@ -69,6 +69,7 @@ class TrainConfig:
     overlap_teacher: bool = True        # teacher forward on a second HIP stream, concurrent with the student forward
     overlap_wgrad: bool = True          # weight-gradient launches of the backward on a second HIP stream (off the dgrad chain)
     overlap_features: bool = True       # feature branch (projection head, embeddings, FeCL forward + backward) on its own stream
+    fuse_head: bool = True              # V-Net: out_conv fused into block_nine's normalisation passes (Engine._norm_head)
     fuse_finish: bool = False           # small levels: split-K finish of a convolution done by the one-launch norm that follows (Engine.fuse_finish)
     norm_accumulators: bool = False     # two-launch norms through double-atomic accumulators (measured slower: DESIGN.md section 9)
     ddp_force: bool = False             # run the data-parallel exchange with a ONE-rank process group as well (RCCL test on one GPU)
@@ -136,6 +137,7 @@ class DyconTrainer:
         self.s_eng = Engine(cfg.model, self.p, self.g, self.s_buf, cfg.dtype, cfg.feature_scaler, cfg.normalization)
         self.t_eng = Engine(cfg.model, self.t, None, self.t_buf, cfg.dtype, cfg.feature_scaler, cfg.normalization)
         self.s_eng.fuse_finish = self.t_eng.fuse_finish = cfg.fuse_finish
+        self.s_eng.fuse_head = self.t_eng.fuse_head = cfg.fuse_head
         # accumulator form of the norms (engine.use_acc; measured slower, off by default): one arena of zeroed doubles per step,
         # shared by both nets and cleared by ONE launch at the start of the step, before the teacher stream forks
         self.acc_arena = None

@@ -159,6 +159,24 @@ int dycon_norm_bwd_ex(const void* src, int from_y, const void* gy, void* gx, int
                       int defer_dparams, float* workspace, size_t ws_bytes, dycon_stream_t stream);
 int dycon_norm_sum_dparams(const float* workspace, int Nb, int C, float* dgamma, float* dbeta,
                            dycon_stream_t stream);
+/* The 2-class head fused into the V-Net's last normalisation (VNet.py:225-227: block_nine's conv -> norm -> ReLU [-> Dropout3d] ->
+ * out_conv 1x1; train_DyCON_BraTS19.py:304).  C = 16 channels, 2 logits; head_w = out_conv.weight (2,16,1,1,1) fp32 as torch
+ * stores it, head_b = out_conv.bias.  The normalised tensor and its gradient are never written:
+ *   fwd : logits (Nb, V, 2) fp32 = head(act(norm(x)) * chan_scale), statistics from dycon_norm_stats
+ *   bwd : gx = d/dx given g_logits (Nb, V, 2) fp32; dgamma / dbeta as dycon_norm_bwd; the head's weight / bias gradient partials
+ *         stay in `workspace` (dycon_norm_head_workspace bytes) until dycon_norm_head_dparams sums them (any stream).
+ * Per-voxel arithmetic and roundings are those of dycon_norm_apply + dycon_conv_direct (forward) and dycon_conv_direct's data
+ * gradient + dycon_norm_bwd (backward): same logits bit for bit, same gx to fp32 round-off. */
+size_t dycon_norm_head_workspace(int Nb, long long V);
+int dycon_norm_head_fwd(const void* x, int dtype, int Nb, long long V, int G, const float* stats, const float* gamma,
+                        const float* beta, int relu, const float* chan_scale, const float* head_w, const float* head_b,
+                        float* logits, dycon_stream_t stream);
+int dycon_norm_head_bwd(const void* x, const float* g_logits, void* gx, int dtype, int Nb, long long V, int G,
+                        const float* stats, const float* gamma, const float* beta, int relu, const float* chan_scale,
+                        const float* head_w, float* dgamma, float* dbeta, float* workspace, size_t ws_bytes,
+                        dycon_stream_t stream);
+int dycon_norm_head_dparams(const float* workspace, int Nb, long long V, float* d_head_w, float* d_head_b,
+                            dycon_stream_t stream);
 /* Accumulator forms of dycon_norm_fwd / dycon_norm_bwd (from_y = 0): `acc` = dycon_norm_acc_doubles(Nb, V, C) doubles that are
  * ZERO on entry (a slice of an arena the caller clears once per step).  On the shapes that are not served by the one-launch kernels, every chunk of the
  * statistics pass adds its sums to acc (double atomics) and the apply pass forms the group statistics in its prologue: TWO launches

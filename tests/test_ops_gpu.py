@@ -516,3 +516,59 @@ def test_norm_accumulator_form_equals_three_launch_form(kind, C, G, V, dtype):
         tol = 1e-6 if dtype == torch.float32 else 1e-2     # (bf16: one ulp of the stored result where a statistic's last bit differs)
         assert float((a - b).abs().max()) <= tol * float(a.abs().max()) + 1e-9, name
     close(res[0][1], res[1][1], 1e-6, 1e-7, "stats")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("kind", ["gn", "in", "bn"])
+@pytest.mark.parametrize("with_drop", [False, True])
+def test_norm_head_fused_equals_norm_then_head(dtype, kind, with_drop):
+    """dycon_norm_head_fwd / _bwd (block_nine's norm + ReLU + Dropout3d factor + out_conv in the norm's passes) against the
+    launches they replace -- dycon_norm_fwd + dycon_conv_direct forward, dycon_conv_direct's data gradient + dycon_norm_bwd +
+    dycon_conv_wgrad backward: logits bit for bit, gx / dgamma / dbeta to fp32 round-off, the head's weight / bias gradient up to
+    summation order."""
+    from dycon_paper_replication_amd._lib import CONV_1X1
+    rng = np.random.default_rng(zlib.crc32(repr((str(dtype), kind, with_drop)).encode()))
+    B, sp, C = 3, (20, 18, 16), 16
+    V = sp[0] * sp[1] * sp[2]
+    x = torch.from_numpy(rng.standard_normal((B,) + sp + (C,)).astype(np.float32) * 1.5 + 0.3).to(DEV, dtype)
+    gl = torch.from_numpy(rng.standard_normal((B,) + sp + (2,)).astype(np.float32)).to(DEV)
+    W = torch.from_numpy(rng.standard_normal((2, C, 1, 1, 1)).astype(np.float32) * 0.4).to(DEV)
+    hb = torch.from_numpy(rng.standard_normal(2).astype(np.float32)).to(DEV)
+    affine = kind != "in"
+    gamma = torch.from_numpy(rng.standard_normal(C).astype(np.float32) * 0.5 + 1.0).to(DEV) if affine else None
+    beta = torch.from_numpy(rng.standard_normal(C).astype(np.float32) * 0.3).to(DEV) if affine else None
+    Nb, G, Vn = (1, C, B * V) if kind == "bn" else (B, 16, V)
+    cs = None
+    if with_drop:
+        cs = torch.from_numpy((rng.random(Nb * C) > 0.5).astype(np.float32) * 2.0).to(DEV)
+    # ---- the launches the fused pair replaces
+    y, stats = ops.norm_fwd(x, Nb, Vn, C, G, gamma, beta, True, None, cs)
+    w_tcn = W.reshape(2, C).t().contiguous()
+    logits_ref = ops.conv_direct(y, w_tcn, hb, CONV_1X1, 2, torch.float32)
+    gy = ops.conv_direct(gl, W.reshape(2, C).contiguous(), None, CONV_1X1, C, dtype)
+    dg_ref, db_ref = (torch.empty(C, device=DEV), torch.empty(C, device=DEV)) if affine else (None, None)
+    gx_ref = ops.norm_bwd(x, False, gy, stats, Nb, Vn, C, G, gamma, beta, True, dg_ref, db_ref, chan_scale=cs)
+    gw_ref, gb_ref = torch.empty_like(W), torch.empty_like(hb)
+    ops.conv_wgrad(y, gl, gw_ref, CONV_1X1, 0, 1, C, dbias=gb_ref)
+    # ---- fused
+    stats2 = ops.norm_stats(x, Nb, Vn, C, G)
+    assert torch.equal(stats2, stats)
+    logits = ops.norm_head_fwd(x, stats2, Nb, Vn, G, W, hb, gamma, beta, True, cs)
+    dg, db = (torch.empty(C, device=DEV), torch.empty(C, device=DEV)) if affine else (None, None)
+    gx, pend = ops.norm_head_bwd(x, gl, stats2, Nb, Vn, G, W, gamma, beta, True, dg, db, cs)
+    gw, gb = torch.empty_like(W), torch.empty_like(hb)
+    ops.norm_head_dparams(pend, gw, gb)
+    torch.cuda.synchronize()
+    assert torch.equal(logits, logits_ref)
+    # same per-voxel formulas and roundings; the compiler may contract the multiply-adds of the two kernel pairs differently, which
+    # moves the group sums by an fp32 ulp: gx to 1e-5 of its scale (fp32 storage) / one bf16 rounding step
+    scale = float(gx_ref.float().abs().max())
+    err = float((gx.float() - gx_ref.float()).abs().max())
+    assert err <= (1e-5 if dtype == torch.float32 else 2.0 ** -7) * scale, (err, scale)
+    if dtype == torch.bfloat16:
+        assert float((gx != gx_ref).float().mean()) < 1e-3          # ... on a handful of elements
+    if affine:
+        close(dg, dg_ref, 1e-5, 1e-5 * float(dg_ref.abs().max()), "dgamma")
+        close(db, db_ref, 1e-5, 1e-5 * float(db_ref.abs().max()), "dbeta")
+    close(gw, gw_ref, 1e-4, 1e-4 * float(gw_ref.abs().max()), "head weight gradient")
+    close(gb, gb_ref, 1e-4, 1e-4 * float(gb_ref.abs().max()), "head bias gradient")
