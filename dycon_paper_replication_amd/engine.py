@@ -173,6 +173,7 @@ class Engine:
         self.gen = 0                 # bump whenever parameter values change (invalidates packed weights)
         self._packed = {}
         self._jobs, self._jobs_dev, self._packed_gen = [], None, -1
+        self._jobs_split, self._pack_event = False, None
         self.on_param_grads = None   # optional callback(name): called in backward once a layer's parameter gradients are enqueued
         self.wgrad_stream = None     # optional side stream for the weight-gradient launches of the backward (set by the trainer)
         self.feat_stream = None      # optional stream for the feature branch (projection head forward + backward), see forward()
@@ -242,19 +243,47 @@ class Engine:
         self._packed[key] = (self.gen, buf)
         return buf
 
-    def repack(self):
-        """Refresh every registered packed operand in one launch (call after the parameters changed)."""
+    def repack(self, early=None, helper=None):
+        """Refresh every registered packed operand (call after the parameters changed): one launch -- or, with `early` (a layer-name
+        prefix) and `helper` (an idle HIP stream), two: the packs of the `early` layers on the launch stream, everything else on
+        `helper`, whose completion event the forward waits for right before the first layer that is not `early` (pack_ready).
+        The 55 us pack of a V-Net then no longer stands in front of the step's first convolution."""
+        self._pack_event = None
         if not self._jobs or self._packed_gen == self.gen:
             return
-        if self._jobs_dev is None:
-            first = next(iter(self._packed.values()))[1]
-            self._jobs_dev = ops.upload_pack_jobs([j for _, j in self._jobs], first.device)
-        biggest = max(j[6] for _, j in self._jobs)                    # output elements of the largest job
-        ops.pack_batch(self._jobs_dev, len(self._jobs), max(1, min(512, (biggest + 2047) // 2048)))
+        split = early is not None and helper is not None
+        if self._jobs_dev is None or self._jobs_split != split:
+            dev = next(iter(self._packed.values()))[1].device
+            name = lambda key: (key[0][0] if isinstance(key[0], tuple) else key[0])     # noqa: E731  (chunked packs: ((name, tag), ch))
+            first = [j for k, j in self._jobs if split and name(k).startswith(early)]
+            rest = [j for k, j in self._jobs if not (split and name(k).startswith(early))]
+            self._jobs_dev = [(ops.upload_pack_jobs(js, dev), len(js), max(1, min(512, (max(j[6] for j in js) + 2047) // 2048)))
+                              for js in (first, rest) if js]
+            self._jobs_split = split
+        if split and len(self._jobs_dev) == 2:
+            (d0, n0, b0), (d1, n1, b1) = self._jobs_dev
+            ops.pack_batch(d0, n0, b0)
+            ev0, ev1, cur = torch.cuda.Event(), torch.cuda.Event(), ops.cur_stream()
+            ops.rec(lambda: (ev0.record(cur), helper.wait_event(ev0)))       # the update that changed the parameters precedes this point
+            with ops.on_stream(helper, light=True):
+                ops.pack_batch(d1, n1, b1)
+                ops.rec(lambda: ev1.record(helper))
+            self._pack_event = ev1
+        else:
+            for d, n, b in self._jobs_dev:
+                ops.pack_batch(d, n, b)
         for key, _ in self._jobs:
             key = key[0] if isinstance(key[0], tuple) else key        # chunked packs register one job per chunk
             self._packed[key] = (self.gen, self._packed[key][1])
         self._packed_gen = self.gen
+
+    def pack_ready(self):
+        """the packs launched on the helper stream by repack(early=..., helper=...) are needed from here on"""
+        ev = getattr(self, "_pack_event", None)
+        if ev is not None:
+            cur = ops.cur_stream()
+            ops.rec(lambda: cur.wait_event(ev))
+            self._pack_event = None
 
     # ---------------------------------------------------------------- gradient bookkeeping
     # With the feature branch on its own stream (feat_stream) gradients cross streams at the tensor both branches consume
@@ -630,6 +659,7 @@ class Engine:
             return self._norm(f"{name}.conv.1", self._conv(f"{name}.conv.0", t, "deconv"), nk, skip=skip, training=training)
 
         x1 = block("block_one", x, 1, first=True)
+        self.pack_ready()            # (repack with early="block_one.": every other layer's operands were packed on a helper stream)
         x2 = block("block_two", down("block_one_dw", x1), 2)
         x3 = block("block_three", down("block_two_dw", x2), 3)
         x4 = block("block_four", down("block_three_dw", x3), 3)

@@ -69,6 +69,7 @@ class TrainConfig:
     overlap_teacher: bool = True        # teacher forward on a second HIP stream, concurrent with the student forward
     overlap_wgrad: bool = True          # weight-gradient launches of the backward on a second HIP stream (off the dgrad chain)
     overlap_features: bool = True       # feature branch (projection head, embeddings, FeCL forward + backward) on its own stream
+    split_repack: bool = True           # the student's weight repack off the head of the dependent chain (Engine.repack)
     fuse_head: bool = True              # V-Net: out_conv fused into block_nine's normalisation passes (Engine._norm_head)
     fuse_finish: bool = False           # small levels: split-K finish of a convolution done by the one-launch norm that follows (Engine.fuse_finish)
     norm_accumulators: bool = False     # two-launch norms through double-atomic accumulators (measured slower: DESIGN.md section 9)
@@ -345,7 +346,12 @@ class DyconTrainer:
         if self.acc_arena is not None:
             arena = self.acc_arena
             ops.rec(lambda: arena.zero_())
-        self.s_eng.repack()          # all weight packs of the step (student fwd + dgrad, teacher fwd): one launch each
+        # all weight packs of the step (student fwd + dgrad, teacher fwd): one launch per net; the student's is split so that only
+        # block_one's operands are packed in front of the first convolution, the rest on the (idle) weight-gradient stream
+        if c.split_repack and self.s_eng.wgrad_stream is not None:
+            self.s_eng.repack(early="block_one.", helper=self.s_eng.wgrad_stream)
+        else:
+            self.s_eng.repack()
         if not c.overlap_teacher:
             self.t_eng.repack()
         x = volume.reshape(B, D, H, W, 1) if volume.is_contiguous() else volume.contiguous().reshape(B, D, H, W, 1)
