@@ -1567,6 +1567,178 @@ __global__ __launch_bounds__(256, 2) void wgrad_k3_bf16_kernel(const bf16* __res
 }
 
 // ------------------------------------------------------------------------------------------------
+// Weight gradient of the FIRST layer (one input channel -> 16): dW[co][tap] = sum_v gy[v][co] * x[v + tap].
+// It is the last launch of the step's backward (its input is the data gradient of block_one's normalisation) and nothing can
+// overlap it, so its duration is step time.  wgrad_k3_bf16_kernel<1, true> treats the single channel as a 16-channel block
+// (27 MFMAs per 32 voxels at 1/16 utilisation, two barriers per 128-voxel tile, one tile of prefetch: 91 us for 120 MB).
+// Here the product is laid out the other way round: D[tap (32, 27 used)][co (16)] += Xp^T[tap][voxel] . G[voxel][co], TWO MFMAs per
+// 32 voxels; the A fragment of a tap is 8 x-neighbours of the halo row, read with one ds_read_b128 from one of three copies of
+// the (1.2 KB) halo pre-shifted by dx; persistent workgroups walk 4x8x8 tiles with the gy tiles of the next DEPTH tiles in flight
+// in registers.  A pure stream of gy.
+// ------------------------------------------------------------------------------------------------
+#ifndef WC1_DEPTH
+#define WC1_DEPTH 3
+#endif
+__global__ __launch_bounds__(256, 2) void wgrad_k3_c1_kernel(const bf16* __restrict__ X, const bf16* __restrict__ GY,
+                                                             float* __restrict__ part, float* __restrict__ bias_part, int B, int D,
+                                                             int H, int W, int tilesZ, int tilesY, int tilesX, int nTiles) {
+    constexpr int NROW = CL_HZ * CL_HY;                        // 60 halo x-rows
+    __shared__ __attribute__((aligned(16))) unsigned short Xs[3][NROW][8];        // halo rows shifted by dx: Xs[dx][row][e] = x[row][dx + e]
+    __shared__ __attribute__((aligned(16))) unsigned short Gt[CL_NV * 16];        // gy tile, natural order [voxel][16]
+    __shared__ float red[4][32 * 16 + 16];
+    int tile, t_end, t_stride;
+    xcd_tile_range(nTiles, tile, t_end, t_stride);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 15, kg = lane >> 4, q = r >> 2, p = lane & 3;
+    f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    float bsum = 0.f;
+    // this lane's taps: r (first M tile) and 16 + r (second; >= 27: zero rows)
+    int aoff[2];
+    bool aok[2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        const int t = 16 * mt + r;
+        aok[mt] = t < 27;
+        const int tt = aok[mt] ? t : 0;
+        const int dz = tt / 9, dy = (tt / 3) % 3, dx = tt % 3;
+        aoff[mt] = (dx * NROW + dz * CL_HY + dy) * 8;
+    }
+    // halo elements of this thread (600 scalars over 256 threads) and its two 16-byte pieces of the gy tile
+    constexpr int NSX = (CL_NH + 255) / 256;                    // 3
+    int xrel[NSX], xrow[NSX], xhx[NSX];
+    unsigned xneed[NSX];
+#pragma unroll
+    for (int it = 0; it < NSX; ++it) {
+        const int e = min((int)threadIdx.x + 256 * it, CL_NH - 1);
+        const int hx = e % CL_HX, hy = (e / CL_HX) % CL_HY, hz = e / (CL_HX * CL_HY);
+        xrel[it] = ((hz - 1) * H + (hy - 1)) * W + (hx - 1);
+        xrow[it] = hz * CL_HY + hy;
+        xhx[it] = hx;
+        xneed[it] = (1u << hz) | (1u << (6 + hy)) | (1u << (16 + hx));
+    }
+    int grel[2], gofs[2];
+    unsigned gneed[2];
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int e = threadIdx.x + 256 * it;
+        const int v = e >> 1, pc = e & 1;
+        const int vz = v >> 6, vy = (v >> 3) & 7, vx = v & 7;
+        grel[it] = ((vz * H + vy) * W + vx) * 16 + 8 * pc;
+        gofs[it] = v * 16 + 8 * pc;
+        gneed[it] = (1u << (vz + 1)) | (1u << (6 + vy + 1)) | (1u << (16 + vx + 1));    // interior voxel = halo coordinate + 1
+    }
+    struct Geo { long long org; unsigned mask; };
+    auto geometry = [&](int t, Geo& g) {
+        t = min(t, t_end - 1);
+        const int tx = t % tilesX; t /= tilesX;
+        const int ty = t % tilesY; t /= tilesY;
+        const int tz = t % tilesZ;
+        const int b = t / tilesZ;
+        const int z0 = tz * CL_TZ, y0 = ty * CL_TY, x0 = tx * CL_TX;
+        g.org = (((long long)b * D + z0) * H + y0) * W + x0;
+        auto bits = [](int c0, int extent, int n) {
+            const int lo = c0 >= 1 ? 0 : 1, hi = min(n, extent - c0 + 1);
+            return ((1u << hi) - 1u) & ~((1u << lo) - 1u);
+        };
+        g.mask = bits(z0, D, CL_HZ) | (bits(y0, H, CL_HY) << 6) | (bits(x0, W, CL_HX) << 16);
+    };
+    struct Stage { unsigned short x[NSX]; uint4 g[2]; };
+    const unsigned short* Xu = reinterpret_cast<const unsigned short*>(X);
+    auto load_tile = [&](const Geo& g, Stage& st) {            // unconditional loads (an invalid piece reads the tile's origin voxel)
+#pragma unroll
+        for (int it = 0; it < NSX; ++it) {
+            const bool in = (g.mask & xneed[it]) == xneed[it];
+            st.x[it] = Xu[g.org + (in ? xrel[it] : 0)];
+        }
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const bool in = (g.mask & gneed[it]) == gneed[it];
+            st.g[it] = *reinterpret_cast<const uint4*>(GY + g.org * 16 + (in ? grel[it] : 0));
+        }
+    };
+    auto store_tile = [&](const Geo& g, const Stage& st) {
+#pragma unroll
+        for (int it = 0; it < NSX; ++it) {
+            if ((int)threadIdx.x + 256 * it < CL_NH) {
+                const bool in = (g.mask & xneed[it]) == xneed[it];
+                const unsigned short v = in ? st.x[it] : (unsigned short)0;
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) {
+                    const int e = xhx[it] - dx;
+                    if (e >= 0 && e < 8) Xs[dx][xrow[it]][e] = v;
+                }
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const bool in = (g.mask & gneed[it]) == gneed[it];
+            uint4 v = st.g[it];
+            if (!in) v = make_uint4(0, 0, 0, 0);
+            *reinterpret_cast<uint4*>(Gt + gofs[it]) = v;
+        }
+    };
+    auto compute = [&]() {                                      // wave w: z-slice w of the tile = 2 k-steps of 4 x-rows
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int row = wave * 8 + 4 * s + kg;              // x-row (z, y) of the tile, 8 voxels
+            const unsigned short* g0 = Gt + (row * 8 + q) * 16 + 4 * p;
+            const bf16x8 bfr = tr_frag(g0, g0 + 4 * 16);        // B[k = voxel x][n = channel r]
+            if (bias_part != nullptr) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) bsum += (float)bfr[e];
+            }
+            const int hrow = (wave * CL_HY + 4 * s + kg) * 8;   // halo row (z + dz, y + dy) is hrow + (dz * HY + dy) * 8
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                uint4 a = *reinterpret_cast<const uint4*>(&Xs[0][0][0] + aoff[mt] + hrow);
+                if (!aok[mt]) a = make_uint4(0, 0, 0, 0);
+                acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), bfr, acc[mt], 0, 0, 0);
+            }
+        }
+    };
+
+    if (tile < t_end) {
+        Stage st[WC1_DEPTH];
+        Geo gg[WC1_DEPTH];
+#pragma unroll
+        for (int d = 0; d < WC1_DEPTH; ++d) { geometry(tile + d * t_stride, gg[d]); load_tile(gg[d], st[d]); }
+        // tile j of this workgroup travels in set j % DEPTH; the loop is unrolled DEPTH times so that the sets are compile-time
+        for (; tile < t_end; tile += WC1_DEPTH * t_stride) {
+#pragma unroll
+            for (int d = 0; d < WC1_DEPTH; ++d) {
+                if (tile + d * t_stride < t_end) {              // (uniform)
+                    __syncthreads();                            // previous tile consumed
+                    store_tile(gg[d], st[d]);
+                    geometry(tile + (d + WC1_DEPTH) * t_stride, gg[d]);
+                    load_tile(gg[d], st[d]);                    // DEPTH tiles ahead (clamped past the end: loaded, never stored)
+                    __syncthreads();
+                    compute();
+                }
+            }
+        }
+    }
+    // ---- this workgroup's partial: D tile row (tap) = 4 kg + i, column (co) = r; summed over the four waves through LDS
+    __syncthreads();
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) red[wave][(16 * mt + 4 * kg + i) * 16 + r] = acc[mt][i];
+    {
+        float v = bsum;
+        v += __shfl_xor(v, 16, 64);
+        v += __shfl_xor(v, 32, 64);
+        if (kg == 0) red[wave][32 * 16 + r] = v;
+    }
+    __syncthreads();
+    for (int o = threadIdx.x; o < 27 * 16; o += 256)            // part[split][t][ci = 0][co]
+        part[(long long)blockIdx.x * 27 * 16 + o] = red[0][o] + red[1][o] + red[2][o] + red[3][o];
+    if (bias_part != nullptr && threadIdx.x < 16) {
+        const int o = 32 * 16 + threadIdx.x;
+        bias_part[(long long)blockIdx.x * 16 + threadIdx.x] = red[0][o] + red[1][o] + red[2][o] + red[3][o];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // k=2 / stride-2 weight gradient on the bf16 matrix cores (down-convolutions and, with the operand roles swapped,
 // transposed convolutions):   dW[t][c_hi][c_lo] = sum_m  HI[2m + t][c_hi] * LO[m][c_lo],   t = 2x2x2 taps.
 // Same structure as wgrad_k3_bf16_kernel: natural-order LDS tiles, transposed ds_read_b64_tr_b16 fragments;
@@ -2425,9 +2597,18 @@ static bool wgrad_k3_ok(int mode, int Cin, int Cout) {
     return mode == DYCON_CONV_K3 && (Cin % 16 == 0 || Cin == 1) && Cout % 16 == 0 && (Cout == 16 || Cout == 32 || Cout % 64 == 0);
 }
 
+static int wgrad_c1_wgs(int B, int Di, int Hi, int Wi) {      // persistent workgroups (= partial rows) of wgrad_k3_c1_kernel
+    const int nTiles = B * cdiv(Di, CL_TZ) * cdiv(Hi, CL_TY) * cdiv(Wi, CL_TX);
+    return 8 * min(cdiv(nTiles, 8), 64);
+}
+
 extern "C" size_t dycon_conv_wgrad_workspace(int mode, int B, int Di, int Hi, int Wi, int Cin, int Cout) {
     const WgradPlan p = wgrad_plan(mode, B, Di, Hi, Wi, Cin, Cout);
     size_t need = (size_t)p.splits * p.L * sizeof(float);
+    if (mode == DYCON_CONV_K3 && Cin == 1 && Cout == 16) {
+        const size_t n3 = (size_t)wgrad_c1_wgs(B, Di, Hi, Wi) * (p.L + Cout) * sizeof(float);
+        if (n3 > need) need = n3;
+    }
     if (wgrad_k3_ok(mode, Cin, Cout) || wgrad_k2_ok(mode, Cin, Cout)) {
         const WgradK3Plan k = mode == DYCON_CONV_K3 ? wgrad_k3_plan(B, Di, Hi, Wi, Cin, Cout) : wgrad_k2_plan(B, Di, Hi, Wi, Cin, Cout);
         const size_t n2 = ((size_t)k.splits * p.L + (size_t)k.splits * Cout) * sizeof(float);
@@ -2479,6 +2660,18 @@ extern "C" int dycon_conv_wgrad(const void* x, int x_dtype, const void* gy, int 
     const WgradPlan p = wgrad_plan(mode, B, Di, Hi, Wi, Cin, Cout);
     if (x_dtype == DYCON_BF16 && g_dtype == DYCON_BF16 && wgrad_k3_ok(mode, Cin, Cout)) {
         const WgradK3Plan k = wgrad_k3_plan(B, Di, Hi, Wi, Cin, Cout);
+        static const bool wc1_on = env_ll("DYCON_WGRAD_C1", 1) != 0;
+        if (wc1_on && Cin == 1 && Cout == 16) {      // first layer: transposed product, persistent workgroups (wgrad_k3_c1_kernel)
+            const int tz = cdiv(Di, CL_TZ), ty = cdiv(Hi, CL_TY), tx = cdiv(Wi, CL_TX);
+            const int nTiles = B * tz * ty * tx;
+            const int wgs = wgrad_c1_wgs(B, Di, Hi, Wi);
+            float* bp = dbias ? workspace + (size_t)wgs * p.L : nullptr;
+            wgrad_k3_c1_kernel<<<wgs, 256, 0, stream>>>((const bf16*)x, (const bf16*)gy, workspace, bp, B, Di, Hi, Wi, tz, ty, tx, nTiles);
+            DYCON_LAUNCH_CHECK();
+            launch_reduce_partials(workspace, wgs, p.L, dw, Cin, Cout, s_t, s_c, s_n, stream, bp, dbias);
+            DYCON_LAUNCH_CHECK();
+            return DYCON_OK;
+        }
         float* bpart = dbias ? workspace + (size_t)k.splits * p.L : nullptr;
         dim3 grid(k.gx, k.splits);
 #define DYCON_WK3(NTV, C1) \

@@ -50,7 +50,8 @@ def assert_bf16_elementwise(got, ref, what, acc_noise=1e-3):
 
 # kind, cin, cout, spatial -- the layers of the V-Net / U-Net step at 96^3 and 112x112x96, B = 4
 FULL_CASES = [
-    ("k3", 1, 16, (96, 96, 96)),      # conv_k3_c1 (persistent, first layer)
+    ("k3", 1, 16, (96, 96, 96)),      # conv_k3_c1 (persistent, first layer) and wgrad_k3_c1 (its weight gradient)
+    ("k3", 1, 16, (50, 44, 46)),      # ... ragged tiles in all three directions
     ("k3", 16, 16, (96, 96, 96)),     # conv_k3_p16 (persistent, weight-stationary)
     ("k3", 16, 16, (112, 112, 96)),   # Pancreas geometry: partial tiles in H (112 = 14 x 8) ...
     ("k3", 32, 32, (48, 48, 48)),     # conv_k3_p32 (persistent, weights stationary in LDS)

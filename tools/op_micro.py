@@ -89,3 +89,9 @@ both("norm + head fwd, unfused (4 launches)", unfused_fwd, 4 * nb)
 both("norm + head fwd, fused (3 launches)", fused_fwd, 2 * nb)
 both("head dgrad + norm bwd + head wgrad, unfused", unfused_bwd, 8 * nb)
 both("norm_head bwd, fused", fused_bwd, 3 * nb)
+
+# first layer's weight gradient (the last launch of the backward: nothing overlaps it)
+x1 = torch.randn(B, S, S, S, 1, device=dev).bfloat16()
+g16 = torch.randn(B, S, S, S, 16, device=dev).bfloat16()
+gw1, gb1 = torch.empty(16, 1, 3, 3, 3, device=dev), torch.empty(16, device=dev)
+both("wgrad k3 1->16 @96^3 (first layer)", lambda: ops.conv_wgrad(x1, g16, gw1, CONV_K3, 1, 27, 27, dbias=gb1), g16.numel() * 2 + x1.numel() * 2)
