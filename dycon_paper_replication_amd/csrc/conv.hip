@@ -904,6 +904,9 @@ constexpr int P32_BS = 27 * 2 * 64 * 8;                      // packed weights [
 #ifndef P32_BREG
 #define P32_BREG 0                                           // 1: all 54 weight fragments in registers instead of LDS (measured: 32.8 vs 30.5 us)
 #endif
+#ifndef P32_SGB
+#define P32_SGB 2                                            // VALU instructions requested between consecutive MFMAs (0: the compiler's order)
+#endif
 #ifndef P32_PIN
 #define P32_PIN 1                                            // halo pieces pinned inside their taps (0: the compiler places them)
 #endif
@@ -932,7 +935,8 @@ struct P32Geo {             // wave-uniform description of one tile
     unsigned mask;          // bit hz: halo z valid | bit 6 + hy | bit 16 + hx
 };
 
-__global__ __launch_bounds__(256, 1) void conv_k3_p32_kernel(const bf16* __restrict__ X, const bf16* __restrict__ Wf,
+template <int NW>      // waves per workgroup: 4 (one per SIMD) or 8 (two per SIMD: a single wave is vector-issue bound)
+__global__ __launch_bounds__(64 * NW, 1) void conv_k3_p32_kernel(const bf16* __restrict__ X, const bf16* __restrict__ Wf,
                                                              const float* __restrict__ bias, bf16* __restrict__ Y, int B, int D,
                                                              int H, int W, int tilesZ, int tilesY, int tilesX, int nTiles) {
     __shared__ __attribute__((aligned(16))) unsigned short Xh[2 * P32_XH];
@@ -942,8 +946,10 @@ __global__ __launch_bounds__(256, 1) void conv_k3_p32_kernel(const bf16* __restr
     int tile, t_end, t_stride;
     xcd_tile_range(nTiles, tile, t_end, t_stride);
     if (tile >= t_end) return;                               // (uniform)
+    constexpr int NTHR = 64 * NW, YH = NW / 4, MT = 4 / YH;   // y-halves of a z-slice over the waves, m-tiles (y-row pairs) per wave
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 15, kg = lane >> 4;
+    const int zs = wave & 3, yh = wave >> 2;                 // this wave: z-slice zs, y rows [8 / YH * yh, ...)
 #ifdef P32_STAMP
     unsigned long long seg[6] = {0, 0, 0, 0, 0, 0};
     P32_T(k0);
@@ -960,10 +966,10 @@ __global__ __launch_bounds__(256, 1) void conv_k3_p32_kernel(const bf16* __restr
 #else
     // weights: every piece of this thread in flight at once (the packed order IS the fragment order: a linear copy)
     constexpr int NWP = P32_BS / 8;                          // 3456 pieces of 16 B
-    constexpr int NWS = (NWP + 255) / 256;                   // 14 per thread
+    constexpr int NWS = (NWP + NTHR - 1) / NTHR;             // 14 (7) per thread
     uint4 wst[NWS];
 #pragma unroll
-    for (int it = 0; it < NWS; ++it) wst[it] = *reinterpret_cast<const uint4*>(Wf + (long long)min((int)threadIdx.x + 256 * it, NWP - 1) * 8);
+    for (int it = 0; it < NWS; ++it) wst[it] = *reinterpret_cast<const uint4*>(Wf + (long long)min((int)threadIdx.x + NTHR * it, NWP - 1) * 8);
 #endif
 
     // A fragments (the MFMA's B operand): wave w owns z-slice w of the tile, m-tile m = y rows 2m, 2m+1; k-step t = tap t, lane group
@@ -971,19 +977,19 @@ __global__ __launch_bounds__(256, 1) void conv_k3_p32_kernel(const bf16* __restr
     constexpr int MSTEP = 2 * P32_RP * P32_VS;
     int abase[3];
     {
-        const int vb = ((wave * CL_HY + (r >> 3)) * P32_RP + (r & 7)) * P32_VS;
+        const int vb = ((zs * CL_HY + 2 * MT * yh + (r >> 3)) * P32_RP + (r & 7)) * P32_VS;
 #pragma unroll
         for (int dx = 0; dx < 3; ++dx) abase[dx] = vb + dx * P32_VS + 8 * ((kg + (r & 7) + dx) & 3);
     }
     const int bbase = lane * 8;
 
     constexpr int NPC = CL_NH * 4;                           // 2400 halo pieces of 16 B
-    constexpr int NST = (NPC + 255) / 256;                   // per thread (10; pieces past the end duplicate the last one)
+    constexpr int NST = (NPC + NTHR - 1) / NTHR;             // per thread (10 or 5; pieces past the end duplicate the last one)
     int rel[NST], lofs[NST];
     unsigned need[NST];
 #pragma unroll
     for (int it = 0; it < NST; ++it) {
-        const int e = min((int)threadIdx.x + 256 * it, NPC - 1);
+        const int e = min((int)threadIdx.x + NTHR * it, NPC - 1);
         const int hv = e >> 2, pc = e & 3;
         const int hx = hv % CL_HX, hy = (hv / CL_HX) % CL_HY, hz = hv / (CL_HX * CL_HY);
         rel[it] = (((hz - 1) * H + (hy - 1)) * W + (hx - 1)) * 32 + 8 * pc;
@@ -991,7 +997,7 @@ __global__ __launch_bounds__(256, 1) void conv_k3_p32_kernel(const bf16* __restr
         need[it] = (1u << hz) | (1u << (6 + hy)) | (1u << (16 + hx));
     }
     // output: lane (r, kg) holds channels 4 kg .. 4 kg + 3 (+16 for the second n-tile) of voxel r of each of its 4 m-tiles
-    const int obase = ((wave * H + (r >> 3)) * W + (r & 7)) * 32 + 4 * kg;
+    const int obase = ((zs * H + 2 * MT * yh + (r >> 3)) * W + (r & 7)) * 32 + 4 * kg;
     const int ostep = 2 * W * 32;
     float bv[2][4];
 #pragma unroll
@@ -1036,18 +1042,18 @@ __global__ __launch_bounds__(256, 1) void conv_k3_p32_kernel(const bf16* __restr
         const unsigned short* xh = Xh + buf * P32_XH;
         unsigned short* xo = Xh + (buf ^ 1) * P32_XH;
         geometry(cur + 2 * t_stride, gld);                   // (past the end: the last tile again -- loaded and written, never used)
-        f32x4 acc[4][2];
+        f32x4 acc[MT][2];
 #pragma unroll
-        for (int m = 0; m < 4; ++m) { acc[m][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[m][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        for (int m = 0; m < MT; ++m) { acc[m][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[m][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
         constexpr int LA = P32_LA, RING = P32_LA + 1;        // fragments of tap t+LA are requested before the MFMAs of tap t
-        bf16x8 afr[RING][4];
+        bf16x8 afr[RING][MT];
 #if !P32_BREG
         bf16x8 bfr[RING][2];
 #endif
         auto fetch = [&](int n) {
             const int imm = ((n / 9) * CL_HY + (n / 3) % 3) * P32_RP * P32_VS;
 #pragma unroll
-            for (int m = 0; m < 4; ++m)
+            for (int m = 0; m < MT; ++m)
                 afr[n % RING][m] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(xh + abase[n % 3] + imm + m * MSTEP));
 #if !P32_BREG
 #pragma unroll
@@ -1063,13 +1069,21 @@ __global__ __launch_bounds__(256, 1) void conv_k3_p32_kernel(const bf16* __restr
             if (t < NST) load_piece(gld, t, ld);
             else if (t < 2 * NST) store_piece(gst, t - NST, st, xo);
 #pragma unroll
-            for (int m = 0; m < 4; ++m)
+            for (int m = 0; m < MT; ++m)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)   // transposed: D[cout 4 kg + i][voxel r]
 #if P32_BREG
                     acc[m][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bw[t][j], afr[t % RING][m], acc[m][j], 0, 0, 0);
 #else
                     acc[m][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[t % RING][j], afr[t % RING][m], acc[m][j], 0, 0, 0);
+#endif
+#if P32_SGB      // ask for MFMA / LDS read / 2 VALU in turn: an in-order wave hides other work only in the 8 issue cycles an MFMA leaves free
+#pragma unroll
+            for (int gq = 0; gq < MT * 2; ++gq) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, P32_SGB, 0);
+            }
 #endif
 #if P32_PIN
             if (t < 2 * NST) __builtin_amdgcn_sched_barrier(0);
@@ -1078,10 +1092,10 @@ __global__ __launch_bounds__(256, 1) void conv_k3_p32_kernel(const bf16* __restr
         P32_T(t4);
         {
             bf16* yb = Y + gcur.org + obase;
-            const bool zok = gcur.z0 + wave < D, xok = gcur.x0 + (r & 7) < W;
+            const bool zok = gcur.z0 + zs < D, xok = gcur.x0 + (r & 7) < W;
 #pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                if (zok && xok && gcur.y0 + 2 * m + (r >> 3) < H) {
+            for (int m = 0; m < MT; ++m) {
+                if (zok && xok && gcur.y0 + 2 * MT * yh + 2 * m + (r >> 3) < H) {
 #pragma unroll
                     for (int j = 0; j < 2; ++j)
                         st8_untracked(yb + m * ostep + 16 * j, pack_bf16x2(acc[m][j][0] + bv[j][0], acc[m][j][1] + bv[j][1]),
@@ -1108,7 +1122,7 @@ __global__ __launch_bounds__(256, 1) void conv_k3_p32_kernel(const bf16* __restr
 #if !P32_BREG
 #pragma unroll
     for (int it = 0; it < NWS; ++it)
-        if ((int)threadIdx.x + 256 * it < NWP) *reinterpret_cast<uint4*>(Bs + (threadIdx.x + 256 * it) * 8) = wst[it];
+        if ((int)threadIdx.x + NTHR * it < NWP) *reinterpret_cast<uint4*>(Bs + (threadIdx.x + NTHR * it) * 8) = wst[it];
 #endif
 #pragma unroll
     for (int it = 0; it < NST; ++it) store_piece(g0, it, sa, Xh);
@@ -2410,7 +2424,9 @@ extern "C" int dycon_conv_gemm_ex(const void* x, const void* wfrag, const float*
         static const bool p32_on = env_ll("DYCON_P32", 1) != 0;
         if (p32_on && Cin == 32 && Cout == 32 && !accumulate && nTiles >= 1024) {
             const int per_xcd = min(cdiv(nTiles, 8), 32);
-            conv_k3_p32_kernel<<<8 * per_xcd, 256, 0, stream>>>((const bf16*)x, (const bf16*)wfrag, bias, (bf16*)y, B, Di, Hi, Wi, tz, ty, tx, nTiles);
+            static const long long p32_nw = env_ll("DYCON_P32_WAVES", 8);
+            if (p32_nw == 8) conv_k3_p32_kernel<8><<<8 * per_xcd, 512, 0, stream>>>((const bf16*)x, (const bf16*)wfrag, bias, (bf16*)y, B, Di, Hi, Wi, tz, ty, tx, nTiles);
+            else conv_k3_p32_kernel<4><<<8 * per_xcd, 256, 0, stream>>>((const bf16*)x, (const bf16*)wfrag, bias, (bf16*)y, B, Di, Hi, Wi, tz, ty, tx, nTiles);
             DYCON_LAUNCH_CHECK();
             return DYCON_OK;
         }
