@@ -308,7 +308,7 @@ def colsum(x2d_like, out, ws=None):
 def norm_stats(x, Nb, V, C, G, eps=1e-5, running_mean=None, running_var=None, momentum=0.1):
     stats = torch.empty(Nb * G * 2, dtype=torch.float32, device=x.device)
     ws = _ws(query("dycon_norm_workspace", Nb, V, C), x)
-    with _Region("norm_stats", x.numel() * _es(x), 3 * x.numel()):
+    with _Region("norm_fwd", x.numel() * _es(x), 3 * x.numel()):
         call("dycon_norm_stats", _p(x), dt(x), Nb, V, C, G, eps, _p(stats), _p(running_mean), _p(running_var), momentum,
              _p(ws), ws.numel() * 4, _s())
     return stats
