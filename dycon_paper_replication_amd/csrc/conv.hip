@@ -1436,10 +1436,7 @@ __device__ __forceinline__ bf16x8 tr_frag(const unsigned short* lds_lo, const un
     return __builtin_bit_cast(bf16x8, t);
 }
 
-#ifndef WK3_DEPTH
-#define WK3_DEPTH 1                      // (2, 3: measured slower -- the kernel is not waiting for its loads)
-#endif
-template <int NT, bool CIN1, int DEPTH>      // DEPTH: tiles in flight in registers ahead of the one being multiplied
+template <int NT, bool CIN1>
 __global__ __launch_bounds__(256, 2) void wgrad_k3_bf16_kernel(const bf16* __restrict__ X, const bf16* __restrict__ GY,
                                                             float* __restrict__ part, float* __restrict__ bias_part, int B, int D,
                                                             int H, int W, int Cin, int Cout, int nCoBlk, int nTiles, int tilesZ,
@@ -1467,8 +1464,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_k3_bf16_kernel(const bf16* __res
     // the matrix cores work).  CIN1 (first layer, one input channel): channel 0 carries x, channels 1..15 are zero.
     constexpr int NSX = CIN1 ? (WG_NH + 255) / 256 : (WG_NH * 2 + 255) / 256;
     constexpr int NSG = WG_NV * (CB / 8) / 256 > 0 ? WG_NV * (CB / 8) / 256 : 1;
-    uint4 sxs[DEPTH][NSX], sgs[DEPTH][NSG];
-    auto load_tile = [&](int tile, uint4 (&sx)[NSX], uint4 (&sg)[NSG]) {
+    uint4 sx[NSX], sg[NSG];
+    auto load_tile = [&](int tile) {
         int rr = tile;
         const int tx = rr % tilesX; rr /= tilesX;
         const int ty = rr % tilesY; rr /= tilesY;
@@ -1498,7 +1495,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_k3_bf16_kernel(const bf16* __res
                 sg[it] = *reinterpret_cast<const uint4*>(GY + ((((long long)b * D + z) * H + y) * W + x) * Cout + co0 + 8 * v8);
         }
     };
-    auto store_tile = [&](const uint4 (&sx)[NSX], const uint4 (&sg)[NSG]) {
+    auto store_tile = [&]() {
 #pragma unroll
         for (int it = 0; it < NSX; ++it) {
             const int e = threadIdx.x + 256 * it;
@@ -1522,18 +1519,12 @@ __global__ __launch_bounds__(256, 2) void wgrad_k3_bf16_kernel(const bf16* __res
     // workgroup then finds in its XCD's L2
     const int t_per = (nTiles + (int)gridDim.y - 1) / (int)gridDim.y;
     const int t_beg = blockIdx.y * t_per, t_end = min(nTiles, t_beg + t_per);
-#pragma unroll
-    for (int d = 0; d < DEPTH; ++d)
-        if (t_beg + d < t_end) load_tile(t_beg + d, sxs[d], sgs[d]);
-    for (int tile0 = t_beg; tile0 < t_end; tile0 += DEPTH) {
-#pragma unroll
-      for (int d = 0; d < DEPTH; ++d) {          // tile j of this workgroup travels in register set j % DEPTH
-        const int tile = tile0 + d;
-        if (tile >= t_end) break;                // (uniform)
+    if (t_beg < t_end) load_tile(t_beg);
+    for (int tile = t_beg; tile < t_end; ++tile) {
         __syncthreads();   // previous tile fully consumed
-        store_tile(sxs[d], sgs[d]);
+        store_tile();
         __syncthreads();
-        if (tile + DEPTH < t_end) load_tile(tile + DEPTH, sxs[d], sgs[d]);
+        if (tile + 1 < t_end) load_tile(tile + 1);
         // ---- 4 k-steps of 32 voxels: lane group kg owns x-row (z, y) = ((4s+kg)>>2, (4s+kg)&3), voxels x = 0..7
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
@@ -1560,7 +1551,6 @@ __global__ __launch_bounds__(256, 2) void wgrad_k3_bf16_kernel(const bf16* __res
                 }
             }
         }
-      }
     }
     // ---- partial[split][t][ci][co]; D tile: row (ci) = 4*kg + reg, col (co) = lane & 15
     const int col = lane & 15;
@@ -2701,7 +2691,7 @@ extern "C" int dycon_conv_wgrad(const void* x, int x_dtype, const void* gy, int 
         float* bpart = dbias ? workspace + (size_t)k.splits * p.L : nullptr;
         dim3 grid(k.gx, k.splits);
 #define DYCON_WK3(NTV, C1) \
-    wgrad_k3_bf16_kernel<NTV, C1, (NTV <= 2 ? WK3_DEPTH : 1)><<<grid, 256, 0, stream>>>((const bf16*)x, (const bf16*)gy, workspace, bpart, B, Di, Hi, Wi, Cin, Cout, k.nCoBlk, k.nTiles, k.tilesZ, k.tilesY, k.tilesX)
+    wgrad_k3_bf16_kernel<NTV, C1><<<grid, 256, 0, stream>>>((const bf16*)x, (const bf16*)gy, workspace, bpart, B, Di, Hi, Wi, Cin, Cout, k.nCoBlk, k.nTiles, k.tilesZ, k.tilesY, k.tilesX)
         if (Cin == 1) { if (k.NT == 1) DYCON_WK3(1, true); else if (k.NT == 2) DYCON_WK3(2, true); else DYCON_WK3(4, true); }
         else if (k.NT == 1) DYCON_WK3(1, false);
         else if (k.NT == 2) DYCON_WK3(2, false);
