@@ -1593,13 +1593,39 @@ __global__ __launch_bounds__(256, 2) void wgrad_k3_bf16_kernel(const bf16* __res
 #ifndef WC1_DEPTH
 #define WC1_DEPTH 3
 #endif
+// NB ("norm backward on load"): GY is the gradient w.r.t. the OUTPUT of the normalisation that follows the first convolution, Z that
+// normalisation's input; the data gradient gz of the normalisation -- whose only consumer is this weight gradient, the first
+// convolution has no data gradient -- is formed per element while the tile is written to LDS (nb[] = per (sample, channel)
+// {alpha, beta, gamma, p1, p0}: gz = alpha * [p1 z + p0 > 0] gy + beta z + gamma, rounded to bf16 as the stored gz would have been).
+// The backward-apply pass of that normalisation (2 reads + 1 write of the step's largest tensor) and this kernel's read of gz go away.
+struct C1NormBwd { const bf16* Z; const float* stats; const float* gamma; const float* beta; const float* ab; const float* chan_scale;
+                   int Nb, G, relu; float inv_cnt; };
+template <bool NB>
 __global__ __launch_bounds__(256, 2) void wgrad_k3_c1_kernel(const bf16* __restrict__ X, const bf16* __restrict__ GY,
                                                              float* __restrict__ part, float* __restrict__ bias_part, int B, int D,
-                                                             int H, int W, int tilesZ, int tilesY, int tilesX, int nTiles) {
+                                                             int H, int W, int tilesZ, int tilesY, int tilesX, int nTiles,
+                                                             C1NormBwd nbp) {
     constexpr int NROW = CL_HZ * CL_HY;                        // 60 halo x-rows
     __shared__ __attribute__((aligned(16))) unsigned short Xs[3][NROW][8];        // halo rows shifted by dx: Xs[dx][row][e] = x[row][dx + e]
     __shared__ __attribute__((aligned(16))) unsigned short Gt[CL_NV * 16];        // gy tile, natural order [voxel][16]
     __shared__ float red[4][32 * 16 + 16];
+    __shared__ __attribute__((aligned(16))) float nb[NB ? 16 : 1][5][16];          // [sample][constant][channel]
+    if (NB) {
+        for (int i = threadIdx.x; i < B * 16; i += 256) {
+            const int bb = i >> 4, c = i & 15, n = nbp.Nb == 1 ? 0 : bb, g = c / (16 / nbp.G);
+            const float mu = nbp.stats[((long long)n * nbp.G + g) * 2], rs = nbp.stats[((long long)n * nbp.G + g) * 2 + 1];
+            const float gm = nbp.gamma ? nbp.gamma[c] : 1.f, bt = nbp.beta ? nbp.beta[c] : 0.f;
+            const float pa = nbp.ab[((long long)n * nbp.G + g) * 2] * nbp.inv_cnt, pb = nbp.ab[((long long)n * nbp.G + g) * 2 + 1] * nbp.inv_cnt;
+            const float dr = nbp.chan_scale ? nbp.chan_scale[(long long)n * 16 + c] : 1.f;
+            // gz = rs * (gm * g' - (pa + xh * pb)),  xh = (z - mu) * rs,  g' = [gm * xh + bt > 0] * dr * gy
+            nb[bb][0][c] = rs * gm * dr;
+            nb[bb][1][c] = -rs * rs * pb;
+            nb[bb][2][c] = rs * (rs * pb * mu - pa);
+            nb[bb][3][c] = nbp.relu ? gm * rs : 0.f;
+            nb[bb][4][c] = nbp.relu ? bt - gm * rs * mu : 1.f;
+        }
+        __syncthreads();
+    }
     int tile, t_end, t_stride;
     xcd_tile_range(nTiles, tile, t_end, t_stride);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1641,7 +1667,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_k3_c1_kernel(const bf16* __restr
         gofs[it] = v * 16 + 8 * pc;
         gneed[it] = (1u << (vz + 1)) | (1u << (6 + vy + 1)) | (1u << (16 + vx + 1));    // interior voxel = halo coordinate + 1
     }
-    struct Geo { long long org; unsigned mask; };
+    struct Geo { long long org; unsigned mask; int b; };
     auto geometry = [&](int t, Geo& g) {
         t = min(t, t_end - 1);
         const int tx = t % tilesX; t /= tilesX;
@@ -1650,13 +1676,14 @@ __global__ __launch_bounds__(256, 2) void wgrad_k3_c1_kernel(const bf16* __restr
         const int b = t / tilesZ;
         const int z0 = tz * CL_TZ, y0 = ty * CL_TY, x0 = tx * CL_TX;
         g.org = (((long long)b * D + z0) * H + y0) * W + x0;
+        g.b = b;
         auto bits = [](int c0, int extent, int n) {
             const int lo = c0 >= 1 ? 0 : 1, hi = min(n, extent - c0 + 1);
             return ((1u << hi) - 1u) & ~((1u << lo) - 1u);
         };
         g.mask = bits(z0, D, CL_HZ) | (bits(y0, H, CL_HY) << 6) | (bits(x0, W, CL_HX) << 16);
     };
-    struct Stage { unsigned short x[NSX]; uint4 g[2]; };
+    struct Stage { unsigned short x[NSX]; uint4 g[2]; uint4 z[NB ? 2 : 1]; };
     const unsigned short* Xu = reinterpret_cast<const unsigned short*>(X);
     auto load_tile = [&](const Geo& g, Stage& st) {            // unconditional loads (an invalid piece reads the tile's origin voxel)
 #pragma unroll
@@ -1668,6 +1695,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_k3_c1_kernel(const bf16* __restr
         for (int it = 0; it < 2; ++it) {
             const bool in = (g.mask & gneed[it]) == gneed[it];
             st.g[it] = *reinterpret_cast<const uint4*>(GY + g.org * 16 + (in ? grel[it] : 0));
+            if (NB) st.z[it] = *reinterpret_cast<const uint4*>(nbp.Z + g.org * 16 + (in ? grel[it] : 0));
         }
     };
     auto store_tile = [&](const Geo& g, const Stage& st) {
@@ -1687,6 +1715,21 @@ __global__ __launch_bounds__(256, 2) void wgrad_k3_c1_kernel(const bf16* __restr
         for (int it = 0; it < 2; ++it) {
             const bool in = (g.mask & gneed[it]) == gneed[it];
             uint4 v = st.g[it];
+            if (NB) {                                           // gy, z -> gz for this piece's 8 channels of sample g.b
+                const int c0 = 8 * ((threadIdx.x + 256 * it) & 1);
+                Vec16<bf16> gv, zv, o;
+                gv.v = st.g[it];
+                zv.v = st.z[it];
+                const float* tb = &nb[g.b][0][c0];
+#pragma unroll
+                for (int k2 = 0; k2 < 8; ++k2) {
+                    const float z = zv.get(k2);
+                    float gg = gv.get(k2);
+                    if (!(tb[3 * 16 + k2] * z + tb[4 * 16 + k2] > 0.f)) gg = 0.f;
+                    o.set(k2, tb[0 * 16 + k2] * gg + (tb[1 * 16 + k2] * z + tb[2 * 16 + k2]));
+                }
+                v = o.v;
+            }
             if (!in) v = make_uint4(0, 0, 0, 0);
             *reinterpret_cast<uint4*>(Gt + gofs[it]) = v;
         }
@@ -2618,6 +2661,35 @@ static int wgrad_c1_wgs(int B, int Di, int Hi, int Wi) {      // persistent work
     return 8 * min(cdiv(nTiles, 8), 64);
 }
 
+// First layer's weight + bias gradient with the data gradient of the normalisation that follows the first convolution formed on
+// load (wgrad_k3_c1_kernel<true>): gy = gradient w.r.t. that normalisation's output, z = its input, stats / ab = its forward
+// statistics and the {A, B} sums dycon_norm_bwd_stats left behind.  bf16, one input channel, 16 output channels.
+extern "C" size_t dycon_conv1_wgrad_normbwd_workspace(int B, int D, int H, int W) {
+    return (size_t)wgrad_c1_wgs(B, D, H, W) * (27 * 16 + 16) * sizeof(float);
+}
+extern "C" int dycon_conv1_wgrad_normbwd(const void* x, const void* z, const void* gy, int B, int D, int H, int W, int Nb, int G,
+                                         const float* stats, const float* gamma, const float* beta, int relu,
+                                         const float* chan_scale, const float* ab, float* dw, float* dbias, long long s_t,
+                                         long long s_c, long long s_n, float* workspace, size_t ws_bytes, dycon_stream_t stream) {
+    DYCON_REQUIRE(x && z && gy && stats && ab && dw && workspace, "conv1_wgrad_normbwd: null pointer");
+    DYCON_REQUIRE(B > 0 && B <= 16 && D > 0 && H > 0 && W > 0, "conv1_wgrad_normbwd: bad shape (B <= 16)");
+    DYCON_REQUIRE((Nb == B || Nb == 1) && G > 0 && 16 % G == 0, "conv1_wgrad_normbwd: Nb must be B or 1, G must divide 16");
+    DYCON_REQUIRE(ws_bytes >= dycon_conv1_wgrad_normbwd_workspace(B, D, H, W), "conv1_wgrad_normbwd: workspace too small");
+    const int tz = cdiv(D, CL_TZ), ty = cdiv(H, CL_TY), tx = cdiv(W, CL_TX);
+    const int nTiles = B * tz * ty * tx, wgs = wgrad_c1_wgs(B, D, H, W), L = 27 * 16;
+    float* bp = dbias ? workspace + (size_t)wgs * L : nullptr;
+    C1NormBwd nb;
+    nb.Z = (const bf16*)z; nb.stats = stats; nb.gamma = gamma; nb.beta = beta; nb.ab = ab; nb.chan_scale = chan_scale;
+    nb.Nb = Nb; nb.G = G; nb.relu = relu;
+    nb.inv_cnt = 1.f / ((float)((long long)D * H * W * (Nb == 1 ? B : 1)) * (float)(16 / G));
+    wgrad_k3_c1_kernel<true><<<wgs, 256, 0, stream>>>((const bf16*)x, (const bf16*)gy, workspace, bp, B, D, H, W, tz, ty, tx, nTiles, nb);
+    DYCON_LAUNCH_CHECK();
+    launch_reduce_partials(workspace, wgs, L, dw, 1, 16, s_t, s_c, s_n, stream, bp, dbias);
+    DYCON_LAUNCH_CHECK();
+    return DYCON_OK;
+}
+
+
 extern "C" size_t dycon_conv_wgrad_workspace(int mode, int B, int Di, int Hi, int Wi, int Cin, int Cout) {
     const WgradPlan p = wgrad_plan(mode, B, Di, Hi, Wi, Cin, Cout);
     size_t need = (size_t)p.splits * p.L * sizeof(float);
@@ -2682,7 +2754,7 @@ extern "C" int dycon_conv_wgrad(const void* x, int x_dtype, const void* gy, int 
             const int nTiles = B * tz * ty * tx;
             const int wgs = wgrad_c1_wgs(B, Di, Hi, Wi);
             float* bp = dbias ? workspace + (size_t)wgs * p.L : nullptr;
-            wgrad_k3_c1_kernel<<<wgs, 256, 0, stream>>>((const bf16*)x, (const bf16*)gy, workspace, bp, B, Di, Hi, Wi, tz, ty, tx, nTiles);
+            wgrad_k3_c1_kernel<false><<<wgs, 256, 0, stream>>>((const bf16*)x, (const bf16*)gy, workspace, bp, B, Di, Hi, Wi, tz, ty, tx, nTiles, C1NormBwd{});
             DYCON_LAUNCH_CHECK();
             launch_reduce_partials(workspace, wgs, p.L, dw, Cin, Cout, s_t, s_c, s_n, stream, bp, dbias);
             DYCON_LAUNCH_CHECK();

@@ -704,6 +704,33 @@ extern "C" int dycon_norm_bwd(const void* src, int from_y, const void* gy, void*
                              ws_bytes, stream);
 }
 
+// The first two launches of dycon_norm_bwd alone (three-launch shapes): statistics pass + finalize.  dgamma / dbeta are written and the
+// per-group {A, B} sums are left at float offset dycon_norm_bwd_ab_offset(Nb, V, C) of `workspace` for a consumer that forms the data
+// gradient itself (dycon_conv1_wgrad_normbwd: the first layer's weight gradient reads gy and z and never sees a stored gz).
+extern "C" size_t dycon_norm_bwd_ab_offset(int Nb, long long V, int C) {
+    const NormPlan p = norm_plan(V);
+    return (size_t)Nb * p.chunks * C * 2;
+}
+extern "C" int dycon_norm_bwd_stats(const void* src, const void* gy, int dtype, int Nb, long long V, int C, int G, const float* stats,
+                                    const float* gamma, const float* beta, int relu, const float* chan_scale, float* dgamma,
+                                    float* dbeta, float* workspace, size_t ws_bytes, dycon_stream_t stream) {
+    DYCON_REQUIRE(src && gy && stats && workspace, "norm_bwd_stats: null pointer");
+    if (int e = norm_check("norm_bwd_stats", dtype, Nb, V, C, G)) return e;
+    DYCON_REQUIRE(ws_bytes >= dycon_norm_workspace(Nb, V, C), "norm_bwd_stats: workspace too small");
+    const NormPlan p = norm_plan(V);
+    float* ab = workspace + dycon_norm_bwd_ab_offset(Nb, V, C);
+    dim3 grid(p.chunks, Nb);
+    DYCON_DISPATCH(dtype, {
+        norm_partial_kernel<T, 1><<<grid, 256, 0, stream>>>((const T*)src, (const T*)gy, workspace, V, C, G, p.rows_per_chunk,
+                                                            stats, gamma, beta, relu, 0, chan_scale);
+    });
+    DYCON_LAUNCH_CHECK();
+    const int nfin = Nb * G + ((dgamma || dbeta) ? C : 0);
+    norm_finalize_bwd_kernel<<<nfin, 256, 0, stream>>>(workspace, Nb, p.chunks, C, G, gamma, ab, dgamma, dbeta);
+    DYCON_LAUNCH_CHECK();
+    return DYCON_OK;
+}
+
 // the per-sample {dbeta, dgamma} contributions a deferred one-launch backward left in its workspace -> dgamma / dbeta
 extern "C" int dycon_norm_sum_dparams(const float* workspace, int Nb, int C, float* dgamma, float* dbeta, dycon_stream_t stream) {
     DYCON_REQUIRE(workspace && Nb > 0 && C > 0 && (dgamma || dbeta), "norm_sum_dparams: bad arguments");

@@ -196,6 +196,7 @@ class Engine:
         # fp32 slabs in 32-byte pieces at a C*4-byte stride where splitk_finish streams them fully coalesced.  Off by default.
         self.fuse_finish = False
         self.fuse_head = True            # V-Net: the 2-class head inside the last normalisation's passes (_norm_head)
+        self.fuse_first = True           # V-Net: block_one's norm backward formed on load by the first layer's weight gradient (_first_block)
         self._deferred = {}
         self._pending_dparams = []
         self.tape = []
@@ -516,6 +517,61 @@ class Engine:
             self.tape.append(bwd)
         return y
 
+    def _first_block(self, name, x, kind, training):
+        """block_one (conv 1 -> 16, norm, ReLU; VNet.py:176): the normalisation's data gradient has ONE consumer, the convolution's weight
+        gradient (the image needs no gradient), so the backward never stores it: norm statistics pass + finalize on the chain, then the
+        weight gradient forms it on load (csrc/conv.hip, wgrad_k3_c1_kernel<true>) -- the backward-apply pass over the step's largest
+        tensor and the weight gradient's read of its result are gone from the exposed tail of the backward."""
+        cname, nname = f"{name}.conv.0", f"{name}.conv.1"
+        rec, self.recording = self.recording, False
+        try:
+            z = self._conv(cname, x, "k3", need_gx=False)
+        finally:
+            self.recording = rec
+        B, C = z.shape[0], z.shape[-1]
+        V = z.numel() // (B * C)
+        gamma = beta = rm = rv = None
+        if kind == "gn":
+            Nb, G = B, 16
+            gamma, beta = self.p[nname + ".weight"], self.p[nname + ".bias"]
+        elif kind == "in":
+            Nb, G = B, C
+        else:
+            Nb, G, V = 1, C, B * V
+            gamma, beta = self.p[nname + ".weight"], self.p[nname + ".bias"]
+            rm, rv = self.buf.get(nname + ".running_mean"), self.buf.get(nname + ".running_var")
+        upd = kind == "bn" and training and self.update_bn
+        y, stats = ops.norm_fwd(z, Nb, V, C, G, gamma, beta, True, None, None, 1e-5, rm if upd else None, rv if upd else None, 0.1)
+        if upd and nname + ".num_batches_tracked" in self.buf:
+            nbt = self.buf[nname + ".num_batches_tracked"]
+            ops.rec(lambda: nbt.add_(1))
+        if rec:
+            def bwd():
+                gy = self._take(y)
+                dg = self.g[nname + ".weight"] if gamma is not None else None
+                db = self.g[nname + ".bias"] if beta is not None else None
+                nws, ab = ops.norm_bwd_stats(z, gy, stats, Nb, V, C, G, gamma, beta, True, dg, db)
+                gw, gb = self.g[cname + ".weight"], self.g[cname + ".bias"]
+                wws = self._wws.get(cname + "#nb")
+                if wws is None:
+                    wws = self._wws[cname + "#nb"] = ops._ws(ops.query("dycon_conv1_wgrad_normbwd_workspace", *x.shape[:4]), x)
+                if self.wgrad_stream is not None:
+                    ev, cs, ws_ = torch.cuda.Event(), ops.cur_stream(), self.wgrad_stream
+                    ops.rec(lambda: (ev.record(cs), ws_.wait_event(ev)))
+                    with ops.on_stream(self.wgrad_stream, light=True):
+                        self._flush_dparams()
+                        ops.conv1_wgrad_normbwd(x, z, gy, stats, ab, Nb, G, gw, gb, gamma, beta, True, None, ws=wws)
+                    for t in (gy, nws):
+                        t.record_stream(self.wgrad_stream)
+                else:
+                    ops.conv1_wgrad_normbwd(x, z, gy, stats, ab, Nb, G, gw, gb, gamma, beta, True, None, ws=wws)
+                if self.on_param_grads is not None:
+                    if gamma is not None:
+                        self.on_param_grads(nname + ".weight")
+                    self.on_param_grads(cname + ".weight")
+            self.tape.append(bwd)
+        return y
+
     def _norm_head(self, prefix, z, kind, head, training=True, chan_scale=None):
         """block_nine's norm -> ReLU [-> Dropout3d] -> out_conv (VNet.py:225-227) as ONE pass over the pre-norm tensor, forward and
         backward: the normalised 16-channel tensor (the largest activation of the step) and its gradient are never written
@@ -658,7 +714,12 @@ class Engine:
         def up(name, t, skip):
             return self._norm(f"{name}.conv.1", self._conv(f"{name}.conv.0", t, "deconv"), nk, skip=skip, training=training)
 
-        x1 = block("block_one", x, 1, first=True)
+        w1 = self.p["block_one.conv.0.weight"]
+        if (self.fuse_first and self.dtype == torch.bfloat16 and nk != "none" and not (nk == "bn" and not training)
+                and w1.shape[0] == 16 and w1.shape[1] == 1 and x.shape[0] <= 16):
+            x1 = self._first_block("block_one", x, nk, training)
+        else:
+            x1 = block("block_one", x, 1, first=True)
         self.pack_ready()            # (repack with early="block_one.": every other layer's operands were packed on a helper stream)
         x2 = block("block_two", down("block_one_dw", x1), 2)
         x3 = block("block_three", down("block_two_dw", x2), 3)

@@ -400,6 +400,27 @@ def norm_head_dparams(pending, d_head_w, d_head_b):
     call("dycon_norm_head_dparams", _p(ws), Nb, V, _p(d_head_w), _p(d_head_b), _s())
 
 
+def norm_bwd_stats(src, gy, stats, Nb, V, C, G, gamma=None, beta=None, relu=True, dgamma=None, dbeta=None, chan_scale=None):
+    """statistics pass + finalize of the norm backward only; returns (workspace, ab) -- ab = the per-group {A, B} sums (a view)"""
+    ws = _ws(query("dycon_norm_workspace", Nb, V, C), gy)
+    with _Region("norm_bwd", gy.numel() * _es(gy) * 2, 6 * gy.numel()):
+        call("dycon_norm_bwd_stats", _p(src), _p(gy), dt(gy), Nb, V, C, G, _p(stats), _p(gamma), _p(beta), int(relu), _p(chan_scale),
+             _p(dgamma), _p(dbeta), _p(ws), ws.numel() * 4, _s())
+    off = query("dycon_norm_bwd_ab_offset", Nb, V, C)
+    return ws, ws[off:off + Nb * G * 2]
+
+
+def conv1_wgrad_normbwd(x, z, gy, stats, ab, Nb, G, dw, dbias, gamma=None, beta=None, relu=True, chan_scale=None, ws=None):
+    """weight + bias gradient of the first (1 -> 16, k=3, bf16) convolution with the following normalisation's data gradient formed on load"""
+    B, D, H, W, _ = x.shape
+    if ws is None:
+        ws = _ws(query("dycon_conv1_wgrad_normbwd_workspace", B, D, H, W), x)
+    with _Region("wgrad_k3_bf16", (x.numel() + z.numel() + gy.numel()) * 2 + 27 * 16 * 4, 2 * (gy.numel() // 16) * 27 * 16):
+        call("dycon_conv1_wgrad_normbwd", _p(x), _p(z), _p(gy), B, D, H, W, Nb, G, _p(stats), _p(gamma), _p(beta), int(relu),
+             _p(chan_scale), _p(ab), _p(dw), _p(dbias), 1, 27, 27, _p(ws), ws.numel() * 4, _s())
+    return dw
+
+
 def norm_sum_dparams(pending):
     """finish a deferred norm_bwd (ops.norm_bwd(..., defer_dparams=True)) on the CURRENT launch stream"""
     ws, Nb, C, dgamma, dbeta = pending

@@ -177,6 +177,23 @@ int dycon_norm_head_bwd(const void* x, const float* g_logits, void* gx, int dtyp
                         dycon_stream_t stream);
 int dycon_norm_head_dparams(const float* workspace, int Nb, long long V, float* d_head_w, float* d_head_b,
                             dycon_stream_t stream);
+/* The normalisation after the FIRST convolution (block_one, VNet.py:176) has one consumer of its data gradient: that convolution's
+ * weight gradient (the image needs none).  So the gradient is never stored:
+ *   dycon_norm_bwd_stats     = the first two launches of dycon_norm_bwd (statistics pass + finalize): dgamma / dbeta, and the per-group
+ *                              {A, B} sums at float offset dycon_norm_bwd_ab_offset(Nb, V, C) of `workspace` (dycon_norm_workspace bytes);
+ *   dycon_conv1_wgrad_normbwd = weight + bias gradient of a 1 -> 16 channel k=3 convolution (bf16) reading x (the image), gy (gradient
+ *                              w.r.t. the normalisation's output) and z (its input); gz = norm-backward(gy, z) is formed per element on
+ *                              load, rounded to bf16 as the stored tensor would have been.  dw layout as dycon_conv_wgrad.
+ * Replaces the backward-apply pass (2 reads + 1 write of the step's largest tensor) and the weight gradient's read of its result. */
+size_t dycon_norm_bwd_ab_offset(int Nb, long long V, int C);
+int dycon_norm_bwd_stats(const void* src, const void* gy, int dtype, int Nb, long long V, int C, int G, const float* stats,
+                         const float* gamma, const float* beta, int relu, const float* chan_scale, float* dgamma,
+                         float* dbeta, float* workspace, size_t ws_bytes, dycon_stream_t stream);
+size_t dycon_conv1_wgrad_normbwd_workspace(int B, int D, int H, int W);
+int dycon_conv1_wgrad_normbwd(const void* x, const void* z, const void* gy, int B, int D, int H, int W, int Nb, int G,
+                              const float* stats, const float* gamma, const float* beta, int relu, const float* chan_scale,
+                              const float* ab, float* dw, float* dbias, long long s_t, long long s_c, long long s_n,
+                              float* workspace, size_t ws_bytes, dycon_stream_t stream);
 /* Accumulator forms of dycon_norm_fwd / dycon_norm_bwd (from_y = 0): `acc` = dycon_norm_acc_doubles(Nb, V, C) doubles that are
  * ZERO on entry (a slice of an arena the caller clears once per step).  On the shapes that are not served by the one-launch kernels, every chunk of the
  * statistics pass adds its sums to acc (double atomics) and the apply pass forms the group statistics in its prologue: TWO launches

@@ -572,3 +572,42 @@ def test_norm_head_fused_equals_norm_then_head(dtype, kind, with_drop):
         close(db, db_ref, 1e-5, 1e-5 * float(db_ref.abs().max()), "dbeta")
     close(gw, gw_ref, 1e-4, 1e-4 * float(gw_ref.abs().max()), "head weight gradient")
     close(gb, gb_ref, 1e-4, 1e-4 * float(gb_ref.abs().max()), "head bias gradient")
+
+
+@pytest.mark.parametrize("kind", ["gn", "in", "bn"])
+@pytest.mark.parametrize("sp", [(24, 20, 28), (10, 9, 13)])
+def test_first_layer_wgrad_with_norm_backward_on_load(kind, sp):
+    """dycon_norm_bwd_stats + dycon_conv1_wgrad_normbwd (block_one: the normalisation's data gradient formed on load by the first
+    convolution's weight gradient, never stored) against dycon_norm_bwd + dycon_conv_wgrad: dgamma / dbeta to fp32 round-off,
+    dW / db to the noise of re-rounding the folded gz to bf16."""
+    from dycon_paper_replication_amd._lib import CONV_K3
+    rng = np.random.default_rng(zlib.crc32(repr((kind, sp)).encode()))
+    B, C = 3, 16
+    V = sp[0] * sp[1] * sp[2]
+    x = torch.from_numpy(rng.standard_normal((B,) + sp + (1,)).astype(np.float32)).to(DEV, torch.bfloat16)
+    z = torch.from_numpy(rng.standard_normal((B,) + sp + (C,)).astype(np.float32) * 1.3 + 0.2).to(DEV, torch.bfloat16)
+    gy = torch.from_numpy(rng.standard_normal((B,) + sp + (C,)).astype(np.float32)).to(DEV, torch.bfloat16)
+    affine = kind != "in"
+    gamma = torch.from_numpy(rng.standard_normal(C).astype(np.float32) * 0.5 + 1.0).to(DEV) if affine else None
+    beta = torch.from_numpy(rng.standard_normal(C).astype(np.float32) * 0.3).to(DEV) if affine else None
+    Nb, G, Vn = (1, C, B * V) if kind == "bn" else (B, 16, V)
+    _, stats = ops.norm_fwd(z, Nb, Vn, C, G, gamma, beta, True)
+    mk = lambda: (torch.empty(C, device=DEV), torch.empty(C, device=DEV)) if affine else (None, None)   # noqa: E731
+    dg_ref, db_ref = mk()
+    gz = ops.norm_bwd(z, False, gy, stats, Nb, Vn, C, G, gamma, beta, True, dg_ref, db_ref)
+    gw_ref, gb_ref = torch.empty(C, 1, 3, 3, 3, device=DEV), torch.empty(C, device=DEV)
+    ops.conv_wgrad(x, gz, gw_ref, CONV_K3, 1, 27, 27, dbias=gb_ref)
+    dg, db = mk()
+    _, ab = ops.norm_bwd_stats(z, gy, stats, Nb, Vn, C, G, gamma, beta, True, dg, db)
+    gw, gb = torch.empty_like(gw_ref), torch.empty_like(gb_ref)
+    ops.conv1_wgrad_normbwd(x, z, gy, stats, ab, Nb, G, gw, gb, gamma, beta, True)
+    torch.cuda.synchronize()
+    if affine:      # same launches on the three-launch shapes; the small shape's reference is the one-launch norm backward (other summation order)
+        close(dg, dg_ref, 1e-5, 1e-5 * float(dg_ref.abs().max()), "dgamma")
+        close(db, db_ref, 1e-5, 1e-5 * float(db_ref.abs().max()), "dbeta")
+    sw, sb = float(gw_ref.abs().max()), float(gb_ref.abs().max())
+    assert float((gw - gw_ref).abs().max()) <= 2e-3 * sw, (float((gw - gw_ref).abs().max()), sw)
+    # the bias gradient is sum(gz) over B*V voxels, analytically ~0 per group (the norm backward removes the mean): what is left is
+    # rounding noise, so the bound is a fraction of sqrt(B*V) bf16 half-steps of rms(gz), not a relative one
+    noise = 0.05 * (B * V) ** 0.5 * 2.0 ** -8 * float(gz.float().pow(2).mean().sqrt())
+    assert float((gb - gb_ref).abs().max()) <= 2e-3 * sb + noise, (float((gb - gb_ref).abs().max()), sb, noise)
