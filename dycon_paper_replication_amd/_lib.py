@@ -47,6 +47,9 @@ SIGNATURES = {
     "dycon_norm_head_fwd": (I, [P, I, I, L, I, P, P, P, I, P, P, P, P, P]),
     "dycon_norm_head_bwd": (I, [P, P, P, I, I, L, I, P, P, P, I, P, P, P, P, P, Z, P]),
     "dycon_norm_head_dparams": (I, [P, I, L, P, P, P]),
+    "dycon_conv_stats_chunks": (I, [I, I, I, I, I, I, I, I]),
+    "dycon_conv_gemm_stats": (I, [P, P, P, P, I, I, I, I, I, I, I, P, Z, P]),
+    "dycon_norm_fwd_parts": (I, [P, P, I, I, L, I, I, F, P, P, P, I, P, P, P, P, F, P, I, P]),
     "dycon_norm_bwd_ab_offset": (Z, [I, L, I]),
     "dycon_norm_bwd_stats": (I, [P, P, I, I, L, I, I, P, P, P, I, P, P, P, P, Z, P]),
     "dycon_conv1_wgrad_normbwd_workspace": (Z, [I, I, I, I]),

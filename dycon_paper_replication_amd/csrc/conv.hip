@@ -933,18 +933,25 @@ struct P32Geo {             // wave-uniform description of one tile
     long long org;          // element offset of voxel (b, z0, y0, x0), 32 channels per voxel
     int z0, y0, x0;
     unsigned mask;          // bit hz: halo z valid | bit 6 + hy | bit 16 + hx
+    int b;                  // sample
 };
 
 template <int NW>      // waves per workgroup: 4 (one per SIMD) or 8 (two per SIMD: a single wave is vector-issue bound)
 __global__ __launch_bounds__(64 * NW, 1) void conv_k3_p32_kernel(const bf16* __restrict__ X, const bf16* __restrict__ Wf,
                                                              const float* __restrict__ bias, bf16* __restrict__ Y, int B, int D,
-                                                             int H, int W, int tilesZ, int tilesY, int tilesX, int nTiles) {
+                                                             int H, int W, int tilesZ, int tilesY, int tilesX, int nTiles,
+                                                             float* __restrict__ stat_part) {
     __shared__ __attribute__((aligned(16))) unsigned short Xh[2 * P32_XH];
 #if !P32_BREG
     __shared__ __attribute__((aligned(16))) unsigned short Bs[P32_BS];
 #endif
     int tile, t_end, t_stride;
     xcd_tile_range(nTiles, tile, t_end, t_stride);
+    // stat_part: per-(sample, workgroup) {sum, sum of squares} of the STORED (bf16) outputs per channel, [B][gridDim.x][32][2] -- the
+    // statistics pass of the normalisation that follows (norm_partial_kernel) then does not run: a persistent workgroup adds up its ~7
+    // tiles in registers and writes one row per sample it touched (rows of the other samples: zero)
+    if (stat_part != nullptr && threadIdx.x < 64)
+        for (int n = 0; n < B; ++n) stat_part[((long long)n * gridDim.x + blockIdx.x) * 64 + threadIdx.x] = 0.f;
     if (tile >= t_end) return;                               // (uniform)
     constexpr int NTHR = 64 * NW, YH = NW / 4, MT = 4 / YH;   // y-halves of a z-slice over the waves, m-tiles (y-row pairs) per wave
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1013,6 +1020,7 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_k3_p32_kernel(const bf16* __r
         const int b = t / tilesZ;
         g.z0 = tz * CL_TZ; g.y0 = ty * CL_TY; g.x0 = tx * CL_TX;
         g.org = ((((long long)b * D + g.z0) * H + g.y0) * W + g.x0) * 32;
+        g.b = b;
         // valid halo coordinates h: 0 <= c0 + h - 1 < extent  <=>  h in [max(0, 1 - c0), min(n, extent - c0 + 1))
         auto bits = [](int c0, int extent, int n) {
             const int lo = c0 >= 1 ? 0 : 1, hi = min(n, extent - c0 + 1);
@@ -1031,6 +1039,34 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_k3_p32_kernel(const bf16* __r
         uint4 v = stg[it];
         if (!in) v = make_uint4(0, 0, 0, 0);
         *reinterpret_cast<uint4*>(img + lofs[it]) = v;
+    };
+
+    float st1[2][4], st2[2][4];                              // this lane's channels 16 j + 4 kg + i, summed over its voxels of the current sample
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) st1[j][i] = st2[j][i] = 0.f;
+    int stat_b = -1;
+    __shared__ float sred[NW * 64];
+    auto flush_stats = [&](int bsample) {                    // uniform call: all threads, between two tiles
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float a = st1[j][i], q2 = st2[j][i];
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) { a += __shfl_xor(a, o, 64); q2 += __shfl_xor(q2, o, 64); }
+                if (r == 0) { sred[(wave * 32 + 16 * j + 4 * kg + i) * 2] = a; sred[(wave * 32 + 16 * j + 4 * kg + i) * 2 + 1] = q2; }
+                st1[j][i] = st2[j][i] = 0.f;
+            }
+        __syncthreads();
+        if (threadIdx.x < 64) {
+            float v = 0.f;
+            for (int w = 0; w < NW; ++w) v += sred[w * 64 + threadIdx.x];
+            stat_part[((long long)bsample * gridDim.x + blockIdx.x) * 64 + threadIdx.x] = v;
+        }
+        __syncthreads();
     };
 
     // One tile.  Halo pieces of the two tiles ahead travel in two register sets: set `ld` receives tile n+2 during taps 0..9 (one
@@ -1097,9 +1133,17 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_k3_p32_kernel(const bf16* __r
             for (int m = 0; m < MT; ++m) {
                 if (zok && xok && gcur.y0 + 2 * MT * yh + 2 * m + (r >> 3) < H) {
 #pragma unroll
-                    for (int j = 0; j < 2; ++j)
-                        st8_untracked(yb + m * ostep + 16 * j, pack_bf16x2(acc[m][j][0] + bv[j][0], acc[m][j][1] + bv[j][1]),
-                                      pack_bf16x2(acc[m][j][2] + bv[j][2], acc[m][j][3] + bv[j][3]));
+                    for (int j = 0; j < 2; ++j) {
+                        const unsigned lo = pack_bf16x2(acc[m][j][0] + bv[j][0], acc[m][j][1] + bv[j][1]);
+                        const unsigned hi = pack_bf16x2(acc[m][j][2] + bv[j][2], acc[m][j][3] + bv[j][3]);
+                        st8_untracked(yb + m * ostep + 16 * j, lo, hi);
+                        if (stat_part != nullptr) {          // (uniform) statistics of the values as stored
+                            const float v0 = __uint_as_float(lo << 16), v1 = __uint_as_float(lo & 0xffff0000u);
+                            const float v2 = __uint_as_float(hi << 16), v3 = __uint_as_float(hi & 0xffff0000u);
+                            st1[j][0] += v0; st2[j][0] += v0 * v0; st1[j][1] += v1; st2[j][1] += v1 * v1;
+                            st1[j][2] += v2; st2[j][2] += v2 * v2; st1[j][3] += v3; st2[j][3] += v3 * v3;
+                        }
+                    }
                 }
             }
         }
@@ -1131,13 +1175,16 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_k3_p32_kernel(const bf16* __r
     P32_T(k1);
 #endif
     for (; tile < t_end; tile += 2 * t_stride) {             // tile j of this workgroup's sequence: image j % 2, store set (j+1) % 2
+        if (stat_part != nullptr && g0.b != stat_b) { if (stat_b >= 0) flush_stats(stat_b); stat_b = g0.b; }
         one_tile(tile, g0, g1, sb, g2, sa, 0);               // computes g0, writes g1's halo (sb), requests g2 into sa
         if (tile + t_stride >= t_end) break;                 // (uniform)
+        if (stat_part != nullptr && g1.b != stat_b) { flush_stats(stat_b); stat_b = g1.b; }
         one_tile(tile + t_stride, g1, g2, sa, g0, sb, 1);    // computes g1, writes g2's halo (sa), requests the next g0 into sb
         g1 = g0;                                             // rotate: the tile just requested is the one after the next
         g0 = g2;
         // after the swap: g0 = the tile to compute, whose halo is in image 0 -- its data travelled in sa; g1 = requested into sb
     }
+    if (stat_part != nullptr && stat_b >= 0) flush_stats(stat_b);
 #ifdef P32_STAMP
     P32_T(k2);
     if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -2425,6 +2472,37 @@ extern "C" int dycon_conv_gemm(const void* x, const void* wfrag, const float* bi
                               stream);
 }
 
+static thread_local float* g_stat_part = nullptr;      // set by dycon_conv_gemm_stats around its call of dycon_conv_gemm_ex
+
+static bool conv_p32_shape(int dtype, int mode, int scatter, int accumulate, int B, int Di, int Hi, int Wi, int Cin, int Cout) {
+    static const bool p32_on = env_ll("DYCON_P32", 1) != 0;
+    const int nTiles = B * cdiv(Di, CL_TZ) * cdiv(Hi, CL_TY) * cdiv(Wi, CL_TX);
+    return p32_on && dtype == DYCON_BF16 && mode == DYCON_CONV_K3 && !scatter && !accumulate && Cin == 32 && Cout == 32 &&
+           (long long)Di * Hi * Wi >= 13824 && nTiles >= 1024;
+}
+// rows per sample of the statistics partials a dycon_conv_gemm_stats call of this shape writes (0: shape not served)
+extern "C" int dycon_conv_stats_chunks(int dtype, int mode, int B, int Di, int Hi, int Wi, int Cin, int Cout) {
+    if (!conv_p32_shape(dtype, mode, 0, 0, B, Di, Hi, Wi, Cin, Cout)) return 0;
+    const int nTiles = B * cdiv(Di, CL_TZ) * cdiv(Hi, CL_TY) * cdiv(Wi, CL_TX);
+    return 8 * min(cdiv(nTiles, 8), 32);
+}
+extern "C" int dycon_conv_gemm_ex(const void* x, const void* wfrag, const float* bias, void* y, int dtype, int mode,
+                                  int scatter, int accumulate, int B, int Di, int Hi, int Wi, int Cin, int N, int Cout,
+                                  float* workspace, size_t ws_bytes, int defer_finish, dycon_stream_t stream);
+// dycon_conv_gemm (k=3, no scatter / accumulation) on a shape dycon_conv_stats_chunks serves, which ALSO leaves per-(sample, chunk,
+// channel) {sum, sum of squares} of the stored outputs in stat_part ([B][chunks][Cout][2] floats): the statistics pass of the
+// normalisation that follows is then dycon_norm_fwd_parts (finalize + apply) instead of a read of the whole tensor.
+extern "C" int dycon_conv_gemm_stats(const void* x, const void* wfrag, const float* bias, void* y, int dtype, int B, int Di, int Hi,
+                                     int Wi, int Cin, int Cout, float* stat_part, size_t stat_bytes, dycon_stream_t stream) {
+    const int chunks = dycon_conv_stats_chunks(dtype, DYCON_CONV_K3, B, Di, Hi, Wi, Cin, Cout);
+    DYCON_REQUIRE(chunks > 0, "conv_gemm_stats: shape not served (ask dycon_conv_stats_chunks)");
+    DYCON_REQUIRE(stat_part && stat_bytes >= (size_t)B * chunks * Cout * 2 * sizeof(float), "conv_gemm_stats: statistics buffer too small");
+    g_stat_part = stat_part;
+    const int rc = dycon_conv_gemm_ex(x, wfrag, bias, y, dtype, DYCON_CONV_K3, 0, 0, B, Di, Hi, Wi, Cin, Cout, Cout, nullptr, 0, 0, stream);
+    g_stat_part = nullptr;
+    return rc;
+}
+
 extern "C" int dycon_conv_gemm_ex(const void* x, const void* wfrag, const float* bias, void* y, int dtype, int mode,
                                   int scatter, int accumulate, int B, int Di, int Hi, int Wi, int Cin, int N, int Cout,
                                   float* workspace, size_t ws_bytes, int defer_finish, dycon_stream_t stream) {
@@ -2468,8 +2546,8 @@ extern "C" int dycon_conv_gemm_ex(const void* x, const void* wfrag, const float*
         if (p32_on && Cin == 32 && Cout == 32 && !accumulate && nTiles >= 1024) {
             const int per_xcd = min(cdiv(nTiles, 8), 32);
             static const long long p32_nw = env_ll("DYCON_P32_WAVES", 8);
-            if (p32_nw == 8) conv_k3_p32_kernel<8><<<8 * per_xcd, 512, 0, stream>>>((const bf16*)x, (const bf16*)wfrag, bias, (bf16*)y, B, Di, Hi, Wi, tz, ty, tx, nTiles);
-            else conv_k3_p32_kernel<4><<<8 * per_xcd, 256, 0, stream>>>((const bf16*)x, (const bf16*)wfrag, bias, (bf16*)y, B, Di, Hi, Wi, tz, ty, tx, nTiles);
+            if (p32_nw == 8) conv_k3_p32_kernel<8><<<8 * per_xcd, 512, 0, stream>>>((const bf16*)x, (const bf16*)wfrag, bias, (bf16*)y, B, Di, Hi, Wi, tz, ty, tx, nTiles, g_stat_part);
+            else conv_k3_p32_kernel<4><<<8 * per_xcd, 256, 0, stream>>>((const bf16*)x, (const bf16*)wfrag, bias, (bf16*)y, B, Di, Hi, Wi, tz, ty, tx, nTiles, g_stat_part);
             DYCON_LAUNCH_CHECK();
             return DYCON_OK;
         }

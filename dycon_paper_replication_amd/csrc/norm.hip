@@ -696,6 +696,19 @@ extern "C" int dycon_norm_apply(const void* x, void* y, int dtype, int Nb, long 
     return DYCON_OK;
 }
 
+// dycon_norm_fwd on the three-launch shapes WITHOUT its statistics pass: `part` holds per-(n, chunk, channel) {sum, sum of squares}
+// partials ([Nb][chunks][C][2] floats) that the producer of x left behind (dycon_conv_gemm_stats); finalize + apply only.
+extern "C" int dycon_norm_fwd_parts(const void* x, void* y, int dtype, int Nb, long long V, int C, int G, float eps, float* stats,
+                                    const float* gamma, const float* beta, int relu, const void* skip, const float* chan_scale,
+                                    float* running_mean, float* running_var, float momentum, const float* part, int chunks,
+                                    dycon_stream_t stream) {
+    DYCON_REQUIRE(x && y && stats && part && chunks > 0, "norm_fwd_parts: bad arguments");
+    if (int e = norm_check("norm_fwd_parts", dtype, Nb, V, C, G)) return e;
+    norm_finalize_stats_kernel<<<Nb * G, 256, 0, stream>>>(part, Nb, chunks, C, G, V, eps, stats, running_mean, running_var, momentum);
+    DYCON_LAUNCH_CHECK();
+    return dycon_norm_apply(x, y, dtype, Nb, V, C, G, stats, gamma, beta, relu, skip, chan_scale, stream);
+}
+
 extern "C" int dycon_norm_bwd(const void* src, int from_y, const void* gy, void* gx, int dtype, int Nb, long long V, int C,
                               int G, const float* stats, const float* gamma, const float* beta, int relu,
                               const float* chan_scale, float* dgamma, float* dbeta, float* workspace, size_t ws_bytes,

@@ -196,6 +196,8 @@ class Engine:
         # fp32 slabs in 32-byte pieces at a C*4-byte stride where splitk_finish streams them fully coalesced.  Off by default.
         self.fuse_finish = False
         self.fuse_head = True            # V-Net: the 2-class head inside the last normalisation's passes (_norm_head)
+        self.conv_stats = True           # 48^3 level: the persistent convolution takes the statistics of its output (ops.conv_gemm_stats)
+        self._stat_parts = {}
         self.fuse_first = True           # V-Net: block_one's norm backward formed on load by the first layer's weight gradient (_first_block)
         self._deferred = {}
         self._pending_dparams = []
@@ -354,7 +356,12 @@ class Engine:
             wf = self._pk((name, "f"), "frag", w, T, Cin, Cout, Cout, 1, T, 0, Cin * T)
             # a GroupNorm / InstanceNorm of the one-launch kind follows (norm_groups > 0): leave a split-K finish to it
             Vo = (x.shape[1] * x.shape[2] * x.shape[3]) // (8 if kind == "k2s2" else 1)
-            if (norm_groups and self.fuse_finish and dtype == torch.bfloat16 and out_dtype == dtype
+            chunks = (ops.conv_stats_chunks(x, Cin, Cout)
+                      if (norm_groups and self.conv_stats and kind == "k3" and out_dtype == dtype) else 0)
+            if chunks:      # the persistent kernel also takes the statistics of its output: the norm that follows skips its statistics pass
+                y, part = ops.conv_gemm_stats(x, wf, b, Cout, chunks)
+                self._stat_parts[id(y)] = (part, chunks)
+            elif (norm_groups and self.fuse_finish and dtype == torch.bfloat16 and out_dtype == dtype
                     and ops.norm_fwd_is_fused(x, Vo, Cout, norm_groups)):
                 y, dc = ops.conv_gemm(x, wf, b, mode, Cout, Cout, defer_finish=True)
                 if dc is not None:
@@ -482,6 +489,9 @@ class Engine:
             # eval-mode BatchNorm (ISLES teacher, train_DyCON_ISLES22.py:114): running statistics
             stats = torch.stack([rm, torch.rsqrt(rv + 1e-5)], 1).reshape(-1).contiguous()
             y = ops.norm_apply(z, stats, Nb, V, C, G, gamma, beta, relu, skip, chan_scale=chan_scale)
+        elif id(z) in self._stat_parts and kind in ("gn", "in"):     # the producing convolution left the statistics partials behind
+            part, chunks = self._stat_parts.pop(id(z))
+            y, stats = ops.norm_fwd_parts(z, part, chunks, Nb, V, C, G, gamma, beta, relu, skip, chan_scale)
         elif id(z) in self._deferred:     # z is still split-K slabs: bias + ordered sum + rounding + norm in ONE launch
             y, stats = ops.norm_fwd_slab(z, self._deferred.pop(id(z)), Nb, V, C, G, gamma, beta, relu, skip, chan_scale)
         else:
@@ -800,6 +810,7 @@ class Engine:
         self.dropout = dropout or DropoutSpec("off")
         self.tape, self.G = [], {}
         self._deferred = {}
+        self._stat_parts = {}
         if self.use_acc and not self.acc_external:        # stand-alone engine (module route, tests): own arena, cleared here
             if self.acc_arena is None:
                 self.acc_arena = torch.empty(self.ACC_DOUBLES, dtype=torch.float64, device=x.device)

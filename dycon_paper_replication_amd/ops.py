@@ -257,6 +257,22 @@ def conv_gemm(x, wfrag, bias, mode, N, Cout, scatter=False, out=None, accumulate
     return out
 
 
+def conv_stats_chunks(x, Cin, Cout):
+    """rows per sample of the statistics partials conv_gemm_stats writes for this k=3 shape (0: not served)"""
+    B, D, H, W, _ = x.shape
+    return query("dycon_conv_stats_chunks", dt(x), CONV_K3, B, D, H, W, Cin, Cout)
+
+
+def conv_gemm_stats(x, wfrag, bias, Cout, chunks):
+    """k=3 convolution that also leaves {sum, sum of squares} partials of its stored outputs: returns (y, part[B][chunks][Cout][2])"""
+    B, D, H, W, Cin = x.shape
+    y = torch.empty((B, D, H, W, Cout), dtype=x.dtype, device=x.device)
+    part = torch.empty(B * chunks * Cout * 2, dtype=torch.float32, device=x.device)
+    with _Region("conv_k3_lds", (x.numel() + y.numel()) * _es(x) + 27 * Cin * Cout * _es(x), 2 * (y.numel() // Cout) * 27 * Cin * Cout):
+        call("dycon_conv_gemm_stats", _p(x), _p(wfrag), _p(bias), _p(y), dt(x), B, D, H, W, Cin, Cout, _p(part), part.numel() * 4, _s())
+    return y, part
+
+
 def conv_direct(x, w_tcn, bias, mode, N, out_dtype, out=None, accumulate=False):
     B, D, H, W, Cin = x.shape
     if out is None:
@@ -329,6 +345,17 @@ def norm_fwd(x, Nb, V, C, G, gamma=None, beta=None, relu=True, skip=None, chan_s
     with _Region("norm_fwd", x.numel() * _es(x) * (4 if skip is not None else 3), 6 * x.numel()):
         call("dycon_norm_fwd", _p(x), _p(y), dt(x), Nb, V, C, G, eps, _p(stats), _p(gamma), _p(beta), int(relu), _p(skip),
              _p(chan_scale), _p(running_mean), _p(running_var), momentum, _p(ws), ws.numel() * 4, _s())
+    return y, stats
+
+
+def norm_fwd_parts(x, part, chunks, Nb, V, C, G, gamma=None, beta=None, relu=True, skip=None, chan_scale=None, eps=1e-5,
+                   running_mean=None, running_var=None, momentum=0.1):
+    """norm_fwd without its statistics pass: finalize the producer's partials (conv_gemm_stats) + apply.  Returns (y, stats)."""
+    y = torch.empty_like(x)
+    stats = torch.empty(Nb * G * 2, dtype=torch.float32, device=x.device)
+    with _Region("norm_fwd", x.numel() * _es(x) * (3 if skip is not None else 2), 3 * x.numel()):
+        call("dycon_norm_fwd_parts", _p(x), _p(y), dt(x), Nb, V, C, G, eps, _p(stats), _p(gamma), _p(beta), int(relu), _p(skip),
+             _p(chan_scale), _p(running_mean), _p(running_var), momentum, _p(part), chunks, _s())
     return y, stats
 
 

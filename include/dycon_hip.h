@@ -185,6 +185,18 @@ int dycon_norm_head_dparams(const float* workspace, int Nb, long long V, float* 
  *                              w.r.t. the normalisation's output) and z (its input); gz = norm-backward(gy, z) is formed per element on
  *                              load, rounded to bf16 as the stored tensor would have been.  dw layout as dycon_conv_wgrad.
  * Replaces the backward-apply pass (2 reads + 1 write of the step's largest tensor) and the weight gradient's read of its result. */
+/* Statistics of a normalisation's input taken by the convolution that produces it.  On the shapes dycon_conv_stats_chunks serves (bf16
+ * k=3 32 -> 32 on >= 1024 tiles: the persistent kernel of the 48^3 level) dycon_conv_gemm_stats is dycon_conv_gemm that also leaves
+ * per-(sample, chunk, channel) {sum, sum of squares} of the values it STORED in stat_part ([B][chunks][Cout][2] floats); the
+ * normalisation that follows is then dycon_norm_fwd_parts = finalize + apply, without the pass that re-reads the tensor
+ * (BatchNorm: Nb = 1, chunks = B * chunks). */
+int dycon_conv_stats_chunks(int dtype, int mode, int B, int Di, int Hi, int Wi, int Cin, int Cout);
+int dycon_conv_gemm_stats(const void* x, const void* wfrag, const float* bias, void* y, int dtype, int B, int Di, int Hi,
+                          int Wi, int Cin, int Cout, float* stat_part, size_t stat_bytes, dycon_stream_t stream);
+int dycon_norm_fwd_parts(const void* x, void* y, int dtype, int Nb, long long V, int C, int G, float eps, float* stats,
+                         const float* gamma, const float* beta, int relu, const void* skip, const float* chan_scale,
+                         float* running_mean, float* running_var, float momentum, const float* part, int chunks,
+                         dycon_stream_t stream);
 size_t dycon_norm_bwd_ab_offset(int Nb, long long V, int C);
 int dycon_norm_bwd_stats(const void* src, const void* gy, int dtype, int Nb, long long V, int C, int G, const float* stats,
                          const float* gamma, const float* beta, int relu, const float* chan_scale, float* dgamma,

@@ -207,3 +207,34 @@ def test_step_full_size_vs_oracle(patch):
             assert 1.0 - cos <= 1.5 * (1.0 - cos_autocast) + 1e-4 and cos >= 0.99 and 0.97 < ratio < 1.03, (cos, cos_autocast, ratio)
         del tr
         torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("sp", [(48, 48, 48), (46, 50, 44)])
+@pytest.mark.parametrize("kind", ["gn", "in"])
+def test_conv_takes_norm_statistics(sp, kind):
+    """dycon_conv_gemm_stats + dycon_norm_fwd_parts (the persistent 48^3 convolution adds up {sum, sum of squares} of the values it
+    stores, the normalisation that follows skips its statistics pass) against dycon_conv_gemm + dycon_norm_fwd: same convolution
+    output bit for bit, statistics to fp32 summation order, normalised output within one bf16 step."""
+    from dycon_paper_replication_amd._lib import CONV_K3
+    rng = np.random.default_rng(zlib.crc32(repr((sp, kind)).encode()))
+    B, C = 4, 32
+    V = sp[0] * sp[1] * sp[2]
+    x = torch.from_numpy(rng.standard_normal((B,) + sp + (C,)).astype(np.float32)).to(DEV, BF)
+    w = torch.from_numpy((rng.standard_normal((C, C, 3, 3, 3)) / np.sqrt(27 * C)).astype(np.float32)).to(DEV)
+    b = torch.from_numpy(rng.standard_normal(C).astype(np.float32)).to(DEV)
+    gamma = torch.from_numpy(rng.standard_normal(C).astype(np.float32) * 0.5 + 1.0).to(DEV) if kind == "gn" else None
+    beta = torch.from_numpy(rng.standard_normal(C).astype(np.float32) * 0.3).to(DEV) if kind == "gn" else None
+    G = 16 if kind == "gn" else C
+    wf = ops.pack_bfrag(w, BF, 27, C, C, C, 1, 27, 0, C * 27)
+    chunks = ops.conv_stats_chunks(x, C, C)
+    assert chunks > 0
+    y_ref = ops.conv_gemm(x, wf, b, CONV_K3, C, C)
+    n_ref, stats_ref = ops.norm_fwd(y_ref, B, V, C, G, gamma, beta, True)
+    y, part = ops.conv_gemm_stats(x, wf, b, C, chunks)
+    n, stats = ops.norm_fwd_parts(y, part, chunks, B, V, C, G, gamma, beta, True)
+    torch.cuda.synchronize()
+    assert torch.equal(y, y_ref)
+    np.testing.assert_allclose(stats.cpu().numpy(), stats_ref.cpu().numpy(), rtol=2e-5, atol=2e-6)
+    err = float((n.float() - n_ref.float()).abs().max())
+    assert err <= 2.0 ** -7 * float(n_ref.float().abs().max()), err
+    assert float((n != n_ref).float().mean()) < 1e-3
