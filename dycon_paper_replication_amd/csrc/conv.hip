@@ -936,7 +936,7 @@ struct P32Geo {             // wave-uniform description of one tile
     int b;                  // sample
 };
 
-template <int NW>      // waves per workgroup: 4 (one per SIMD) or 8 (two per SIMD: a single wave is vector-issue bound)
+template <int NW, bool STATS>      // NW waves per workgroup: 4 (one per SIMD) or 8 (two per SIMD: a single wave is vector-issue bound); STATS: stat_part
 __global__ __launch_bounds__(64 * NW, 1) void conv_k3_p32_kernel(const bf16* __restrict__ X, const bf16* __restrict__ Wf,
                                                              const float* __restrict__ bias, bf16* __restrict__ Y, int B, int D,
                                                              int H, int W, int tilesZ, int tilesY, int tilesX, int nTiles,
@@ -950,7 +950,7 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_k3_p32_kernel(const bf16* __r
     // stat_part: per-(sample, workgroup) {sum, sum of squares} of the STORED (bf16) outputs per channel, [B][gridDim.x][32][2] -- the
     // statistics pass of the normalisation that follows (norm_partial_kernel) then does not run: a persistent workgroup adds up its ~7
     // tiles in registers and writes one row per sample it touched (rows of the other samples: zero)
-    if (stat_part != nullptr && threadIdx.x < 64)
+    if (STATS && threadIdx.x < 64)
         for (int n = 0; n < B; ++n) stat_part[((long long)n * gridDim.x + blockIdx.x) * 64 + threadIdx.x] = 0.f;
     if (tile >= t_end) return;                               // (uniform)
     constexpr int NTHR = 64 * NW, YH = NW / 4, MT = 4 / YH;   // y-halves of a z-slice over the waves, m-tiles (y-row pairs) per wave
@@ -1137,7 +1137,7 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_k3_p32_kernel(const bf16* __r
                         const unsigned lo = pack_bf16x2(acc[m][j][0] + bv[j][0], acc[m][j][1] + bv[j][1]);
                         const unsigned hi = pack_bf16x2(acc[m][j][2] + bv[j][2], acc[m][j][3] + bv[j][3]);
                         st8_untracked(yb + m * ostep + 16 * j, lo, hi);
-                        if (stat_part != nullptr) {          // (uniform) statistics of the values as stored
+                        if (STATS) {          // (uniform) statistics of the values as stored
                             const float v0 = __uint_as_float(lo << 16), v1 = __uint_as_float(lo & 0xffff0000u);
                             const float v2 = __uint_as_float(hi << 16), v3 = __uint_as_float(hi & 0xffff0000u);
                             st1[j][0] += v0; st2[j][0] += v0 * v0; st1[j][1] += v1; st2[j][1] += v1 * v1;
@@ -1175,16 +1175,16 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_k3_p32_kernel(const bf16* __r
     P32_T(k1);
 #endif
     for (; tile < t_end; tile += 2 * t_stride) {             // tile j of this workgroup's sequence: image j % 2, store set (j+1) % 2
-        if (stat_part != nullptr && g0.b != stat_b) { if (stat_b >= 0) flush_stats(stat_b); stat_b = g0.b; }
+        if (STATS && g0.b != stat_b) { if (stat_b >= 0) flush_stats(stat_b); stat_b = g0.b; }
         one_tile(tile, g0, g1, sb, g2, sa, 0);               // computes g0, writes g1's halo (sb), requests g2 into sa
         if (tile + t_stride >= t_end) break;                 // (uniform)
-        if (stat_part != nullptr && g1.b != stat_b) { flush_stats(stat_b); stat_b = g1.b; }
+        if (STATS && g1.b != stat_b) { flush_stats(stat_b); stat_b = g1.b; }
         one_tile(tile + t_stride, g1, g2, sa, g0, sb, 1);    // computes g1, writes g2's halo (sa), requests the next g0 into sb
         g1 = g0;                                             // rotate: the tile just requested is the one after the next
         g0 = g2;
         // after the swap: g0 = the tile to compute, whose halo is in image 0 -- its data travelled in sa; g1 = requested into sb
     }
-    if (stat_part != nullptr && stat_b >= 0) flush_stats(stat_b);
+    if (STATS && stat_b >= 0) flush_stats(stat_b);
 #ifdef P32_STAMP
     P32_T(k2);
     if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -2546,8 +2546,10 @@ extern "C" int dycon_conv_gemm_ex(const void* x, const void* wfrag, const float*
         if (p32_on && Cin == 32 && Cout == 32 && !accumulate && nTiles >= 1024) {
             const int per_xcd = min(cdiv(nTiles, 8), 32);
             static const long long p32_nw = env_ll("DYCON_P32_WAVES", 8);
-            if (p32_nw == 8) conv_k3_p32_kernel<8><<<8 * per_xcd, 512, 0, stream>>>((const bf16*)x, (const bf16*)wfrag, bias, (bf16*)y, B, Di, Hi, Wi, tz, ty, tx, nTiles, g_stat_part);
-            else conv_k3_p32_kernel<4><<<8 * per_xcd, 256, 0, stream>>>((const bf16*)x, (const bf16*)wfrag, bias, (bf16*)y, B, Di, Hi, Wi, tz, ty, tx, nTiles, g_stat_part);
+#define DYCON_P32(NWV, STV) conv_k3_p32_kernel<NWV, STV><<<8 * per_xcd, 64 * NWV, 0, stream>>>((const bf16*)x, (const bf16*)wfrag, bias, (bf16*)y, B, Di, Hi, Wi, tz, ty, tx, nTiles, g_stat_part)
+            if (p32_nw == 8) { if (g_stat_part) DYCON_P32(8, true); else DYCON_P32(8, false); }
+            else { if (g_stat_part) DYCON_P32(4, true); else DYCON_P32(4, false); }
+#undef DYCON_P32
             DYCON_LAUNCH_CHECK();
             return DYCON_OK;
         }

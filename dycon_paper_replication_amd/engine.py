@@ -196,7 +196,8 @@ class Engine:
         # fp32 slabs in 32-byte pieces at a C*4-byte stride where splitk_finish streams them fully coalesced.  Off by default.
         self.fuse_finish = False
         self.fuse_head = True            # V-Net: the 2-class head inside the last normalisation's passes (_norm_head)
-        self.conv_stats = True           # 48^3 level: the persistent convolution takes the statistics of its output (ops.conv_gemm_stats)
+        self.conv_stats = False          # 48^3 level: the persistent convolution takes the statistics of its output (ops.conv_gemm_stats);
+                                         # measured neutral for the step (+5 us per convolution against a 7 us statistics launch): off
         self._stat_parts = {}
         self.fuse_first = True           # V-Net: block_one's norm backward formed on load by the first layer's weight gradient (_first_block)
         self._deferred = {}

@@ -70,7 +70,7 @@ class TrainConfig:
     overlap_wgrad: bool = True          # weight-gradient launches of the backward on a second HIP stream (off the dgrad chain)
     overlap_features: bool = True       # feature branch (projection head, embeddings, FeCL forward + backward) on its own stream
     split_repack: bool = True           # the student's weight repack off the head of the dependent chain (Engine.repack)
-    conv_stats: bool = True             # norm statistics taken by the producing convolution where it is persistent (Engine.conv_stats)
+    conv_stats: bool = False            # norm statistics taken by the producing convolution where it is persistent (measured neutral: off)
     fuse_first: bool = True             # V-Net: block_one's norm backward inside the first layer's weight gradient (Engine._first_block)
     fuse_head: bool = True              # V-Net: out_conv fused into block_nine's normalisation passes (Engine._norm_head)
     fuse_finish: bool = False           # small levels: split-K finish of a convolution done by the one-launch norm that follows (Engine.fuse_finish)
