@@ -52,6 +52,8 @@ SIGNATURES = {
     "dycon_norm_fwd_parts": (I, [P, P, I, I, L, I, I, F, P, P, P, I, P, P, P, P, F, P, I, P]),
     "dycon_norm_bwd_ab_offset": (Z, [I, L, I]),
     "dycon_norm_bwd_stats": (I, [P, P, I, I, L, I, I, P, P, P, I, P, P, P, P, Z, P]),
+    "dycon_first_block_bwd_workspace": (Z, [I, I, I, I]),
+    "dycon_first_block_bwd": (I, [P, P, P, I, I, I, I, I, I, P, P, P, I, P, P, P, P, P, L, L, L, P, Z, P]),
     "dycon_conv1_wgrad_normbwd_workspace": (Z, [I, I, I, I]),
     "dycon_conv1_wgrad_normbwd": (I, [P, P, P, I, I, I, I, I, I, P, P, P, I, P, P, P, P, L, L, L, P, Z, P]),
     "dycon_norm_acc_doubles": (Z, [I, L, I]),

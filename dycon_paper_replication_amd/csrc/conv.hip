@@ -1843,6 +1843,307 @@ __global__ __launch_bounds__(256, 2) void wgrad_k3_c1_kernel(const bf16* __restr
 }
 
 // ------------------------------------------------------------------------------------------------
+// The whole backward of block_one (first convolution 1 -> 16, normalisation, ReLU; VNet.py:176) as ONE pass over (x, z, gy).
+// The normalisation's data gradient is affine in its inputs once the forward statistics are known,
+//     gz = alpha * g' + beta * z + gamma,      g' = [p1 z + p0 > 0] * dr * gy   (forward constants only),
+// with alpha, beta, gamma per (sample, channel) functions of the group sums {sum g', sum g' z} that the SAME pass is taking.  So the
+// first layer's weight gradient  dW[c][t] = sum_v gz[v][c] x[v + t]  is  alpha * GX + beta * ZX + gamma * SX  with three tap
+// correlations  GX = sum g' x,  ZX = sum z x,  SX = sum x  that do not depend on those sums: one streaming pass produces, per
+// (workgroup, sample), GX, ZX, SX and the per-channel sums {sum g', sum g' z, sum z}; a small reduce and a one-workgroup finalize
+// turn them into dW, db, dgamma, dbeta.  Replaces the statistics pass + finalize of the normalisation's backward, the weight-gradient
+// pass and its reduce: (x, z, gy) are read once instead of twice, and nothing of it runs on the weight-gradient stream.  All MFMA
+// operands are exact in bf16 (g' = gy or 0 -- times the power-of-two dropout factor --, z, x), so dW carries no bf16 rounding of gz.
+// Structure of wgrad_k3_c1_kernel: persistent workgroups, transposed product D[tap][column], tiles 3 deep in registers.
+// ------------------------------------------------------------------------------------------------
+constexpr int FB_GX = 0, FB_ZX = 27 * 16, FB_SX = 2 * 27 * 16, FB_SG = FB_SX + 32, FB_SGZ = FB_SG + 16, FB_SZ = FB_SGZ + 16;
+constexpr int FB_ROW = FB_SZ + 16;                            // 944 floats per (sample, workgroup)
+struct FbFwd { const float* stats; const float* gamma; const float* beta; const float* chan_scale; int Nb, G, relu; };
+
+__global__ __launch_bounds__(256, 2) void first_block_bwd_kernel(const bf16* __restrict__ X, const bf16* __restrict__ Z,
+                                                                 const bf16* __restrict__ GY, float* __restrict__ part, int B, int D,
+                                                                 int H, int W, int tilesZ, int tilesY, int tilesX, int nTiles, FbFwd f,
+                                                                 double* __restrict__ tot) {
+    constexpr int NROW = CL_HZ * CL_HY;
+    if (blockIdx.x == 0)                                        // the reduce kernel that follows adds into tot
+        for (int o = threadIdx.x; o < B * FB_ROW; o += 256) tot[o] = 0.0;
+    __shared__ __attribute__((aligned(16))) unsigned short Xs[3][NROW][8];
+    __shared__ __attribute__((aligned(16))) unsigned short Gt1[CL_NV * 16];       // g'
+    __shared__ __attribute__((aligned(16))) unsigned short Gt2[CL_NV * 16];       // z
+    __shared__ float red[4][FB_ROW];
+    __shared__ __attribute__((aligned(16))) float tab[16][3][16];                 // [sample][p1 | p0 | dr][channel]
+    for (int n = 0; n < B; ++n)
+        for (int o = threadIdx.x; o < FB_ROW; o += 256) part[((long long)n * gridDim.x + blockIdx.x) * FB_ROW + o] = 0.f;
+    for (int i = threadIdx.x; i < B * 16; i += 256) {
+        const int bb = i >> 4, c = i & 15, n = f.Nb == 1 ? 0 : bb, g = c / (16 / f.G);
+        const float mu = f.stats[((long long)n * f.G + g) * 2], rs = f.stats[((long long)n * f.G + g) * 2 + 1];
+        const float gm = f.gamma ? f.gamma[c] : 1.f, bt = f.beta ? f.beta[c] : 0.f;
+        tab[bb][0][c] = f.relu ? gm * rs : 0.f;
+        tab[bb][1][c] = f.relu ? bt - gm * rs * mu : 1.f;
+        tab[bb][2][c] = f.chan_scale ? f.chan_scale[(long long)n * 16 + c] : 1.f;
+    }
+    __syncthreads();
+    int tile, t_end, t_stride;
+    xcd_tile_range(nTiles, tile, t_end, t_stride);
+    if (tile >= t_end) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 15, kg = lane >> 4, q = r >> 2, p = lane & 3;
+    f32x4 acc1[2], acc2[2], acc3[2];
+    float sg = 0.f, sgz = 0.f, sz = 0.f;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) acc1[mt] = acc2[mt] = acc3[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    int aoff[2];
+    bool aok[2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        const int t = 16 * mt + r;
+        aok[mt] = t < 27;
+        const int tt = aok[mt] ? t : 0;
+        const int dz = tt / 9, dy = (tt / 3) % 3, dx = tt % 3;
+        aoff[mt] = (dx * NROW + dz * CL_HY + dy) * 8;
+    }
+    constexpr int NSX = (CL_NH + 255) / 256;
+    int xrel[NSX], xrow[NSX], xhx[NSX];
+    unsigned xneed[NSX];
+#pragma unroll
+    for (int it = 0; it < NSX; ++it) {
+        const int e = min((int)threadIdx.x + 256 * it, CL_NH - 1);
+        const int hx = e % CL_HX, hy = (e / CL_HX) % CL_HY, hz = e / (CL_HX * CL_HY);
+        xrel[it] = ((hz - 1) * H + (hy - 1)) * W + (hx - 1);
+        xrow[it] = hz * CL_HY + hy;
+        xhx[it] = hx;
+        xneed[it] = (1u << hz) | (1u << (6 + hy)) | (1u << (16 + hx));
+    }
+    int grel[2], gofs[2];
+    unsigned gneed[2];
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int e = threadIdx.x + 256 * it;
+        const int v = e >> 1, pc = e & 1;
+        const int vz = v >> 6, vy = (v >> 3) & 7, vx = v & 7;
+        grel[it] = ((vz * H + vy) * W + vx) * 16 + 8 * pc;
+        gofs[it] = v * 16 + 8 * pc;
+        gneed[it] = (1u << (vz + 1)) | (1u << (6 + vy + 1)) | (1u << (16 + vx + 1));
+    }
+    struct Geo { long long org; unsigned mask; int b; };
+    auto geometry = [&](int t, Geo& g) {
+        t = min(t, t_end - 1);
+        const int tx = t % tilesX; t /= tilesX;
+        const int ty = t % tilesY; t /= tilesY;
+        const int tz = t % tilesZ;
+        const int b = t / tilesZ;
+        const int z0 = tz * CL_TZ, y0 = ty * CL_TY, x0 = tx * CL_TX;
+        g.org = (((long long)b * D + z0) * H + y0) * W + x0;
+        g.b = b;
+        auto bits = [](int c0, int extent, int n) {
+            const int lo = c0 >= 1 ? 0 : 1, hi = min(n, extent - c0 + 1);
+            return ((1u << hi) - 1u) & ~((1u << lo) - 1u);
+        };
+        g.mask = bits(z0, D, CL_HZ) | (bits(y0, H, CL_HY) << 6) | (bits(x0, W, CL_HX) << 16);
+    };
+    struct Stage { unsigned short x[NSX]; uint4 g[2]; uint4 z[2]; };
+    const unsigned short* Xu = reinterpret_cast<const unsigned short*>(X);
+    auto load_tile = [&](const Geo& g, Stage& st) {
+#pragma unroll
+        for (int it = 0; it < NSX; ++it) {
+            const bool in = (g.mask & xneed[it]) == xneed[it];
+            st.x[it] = Xu[g.org + (in ? xrel[it] : 0)];
+        }
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const bool in = (g.mask & gneed[it]) == gneed[it];
+            st.g[it] = *reinterpret_cast<const uint4*>(GY + g.org * 16 + (in ? grel[it] : 0));
+            st.z[it] = *reinterpret_cast<const uint4*>(Z + g.org * 16 + (in ? grel[it] : 0));
+        }
+    };
+    auto store_tile = [&](const Geo& g, const Stage& st) {
+#pragma unroll
+        for (int it = 0; it < NSX; ++it) {
+            if ((int)threadIdx.x + 256 * it < CL_NH) {
+                const bool in = (g.mask & xneed[it]) == xneed[it];
+                const unsigned short v = in ? st.x[it] : (unsigned short)0;
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) {
+                    const int e = xhx[it] - dx;
+                    if (e >= 0 && e < 8) Xs[dx][xrow[it]][e] = v;
+                }
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const bool in = (g.mask & gneed[it]) == gneed[it];
+            const int c0 = 8 * ((threadIdx.x + 256 * it) & 1);
+            Vec16<bf16> gv, zv, o;
+            gv.v = st.g[it];
+            zv.v = st.z[it];
+            const float* tb = &tab[g.b][0][c0];
+#pragma unroll
+            for (int k2 = 0; k2 < 8; ++k2) {
+                const float z = zv.get(k2);
+                float gg = gv.get(k2) * tb[2 * 16 + k2];
+                if (!(tb[k2] * z + tb[16 + k2] > 0.f)) gg = 0.f;
+                o.set(k2, gg);
+            }
+            uint4 v1 = o.v, v2 = st.z[it];
+            if (!in) { v1 = make_uint4(0, 0, 0, 0); v2 = make_uint4(0, 0, 0, 0); }
+            *reinterpret_cast<uint4*>(Gt1 + gofs[it]) = v1;
+            *reinterpret_cast<uint4*>(Gt2 + gofs[it]) = v2;
+        }
+    };
+    auto compute = [&](unsigned mask) {                         // wave w: z-slice w of the tile = 2 k-steps of 4 x-rows
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int row = wave * 8 + 4 * s + kg;
+            const unsigned short* g1 = Gt1 + (row * 8 + q) * 16 + 4 * p;
+            const unsigned short* g2 = Gt2 + (row * 8 + q) * 16 + 4 * p;
+            const bf16x8 b1 = tr_frag(g1, g1 + 4 * 16);         // g'[k = voxel x][n = channel r]
+            const bf16x8 b2 = tr_frag(g2, g2 + 4 * 16);         // z
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float gg = (float)b1[e], zz = (float)b2[e];
+                sg += gg;
+                sgz += gg * zz;
+                sz += zz;
+            }
+            // column 0 of the third product: 1 for the voxels of this row that lie inside the volume (SX counts x only under those)
+            unsigned xb = (mask >> 17) & 0xffu;
+            if (r != 0 || !((mask >> (wave + 1)) & (mask >> (7 + 4 * s + kg)) & 1u)) xb = 0u;
+            uint4 vw;
+            vw.x = ((xb & 1u) ? 0x3f80u : 0u) | ((xb & 2u) ? 0x3f800000u : 0u);
+            vw.y = ((xb & 4u) ? 0x3f80u : 0u) | ((xb & 8u) ? 0x3f800000u : 0u);
+            vw.z = ((xb & 16u) ? 0x3f80u : 0u) | ((xb & 32u) ? 0x3f800000u : 0u);
+            vw.w = ((xb & 64u) ? 0x3f80u : 0u) | ((xb & 128u) ? 0x3f800000u : 0u);
+            const bf16x8 b3 = __builtin_bit_cast(bf16x8, vw);
+            const int hrow = (wave * CL_HY + 4 * s + kg) * 8;
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                uint4 a = *reinterpret_cast<const uint4*>(&Xs[0][0][0] + aoff[mt] + hrow);
+                if (!aok[mt]) a = make_uint4(0, 0, 0, 0);
+                const bf16x8 af = __builtin_bit_cast(bf16x8, a);
+                acc1[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, b1, acc1[mt], 0, 0, 0);
+                acc2[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, b2, acc2[mt], 0, 0, 0);
+                acc3[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, b3, acc3[mt], 0, 0, 0);
+            }
+        }
+    };
+    auto flush = [&](int n) {                                   // (uniform) this workgroup's sums for sample n -> its row
+        __syncthreads();
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int t = 16 * mt + 4 * kg + i;
+                if (t < 27) {
+                    red[wave][FB_GX + t * 16 + r] = acc1[mt][i];
+                    red[wave][FB_ZX + t * 16 + r] = acc2[mt][i];
+                    if (r == 0) red[wave][FB_SX + t] = acc3[mt][i];
+                }
+            }
+        {
+            float a = sg, b2 = sgz, c2 = sz;
+            a += __shfl_xor(a, 16, 64); a += __shfl_xor(a, 32, 64);
+            b2 += __shfl_xor(b2, 16, 64); b2 += __shfl_xor(b2, 32, 64);
+            c2 += __shfl_xor(c2, 16, 64); c2 += __shfl_xor(c2, 32, 64);
+            if (kg == 0) { red[wave][FB_SG + r] = a; red[wave][FB_SGZ + r] = b2; red[wave][FB_SZ + r] = c2; }
+        }
+        __syncthreads();
+        for (int o = threadIdx.x; o < FB_ROW; o += 256) {
+            if (o >= FB_SX + 27 && o < FB_SG) continue;         // padding
+            part[((long long)n * gridDim.x + blockIdx.x) * FB_ROW + o] = red[0][o] + red[1][o] + red[2][o] + red[3][o];
+        }
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) acc1[mt] = acc2[mt] = acc3[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        sg = sgz = sz = 0.f;
+    };
+
+    Stage st[WC1_DEPTH];
+    Geo gg[WC1_DEPTH];
+    int acc_b = -1;
+#pragma unroll
+    for (int d = 0; d < WC1_DEPTH; ++d) { geometry(tile + d * t_stride, gg[d]); load_tile(gg[d], st[d]); }
+    for (; tile < t_end; tile += WC1_DEPTH * t_stride) {
+#pragma unroll
+        for (int d = 0; d < WC1_DEPTH; ++d) {
+            if (tile + d * t_stride < t_end) {                  // (uniform)
+                const unsigned cur_mask = gg[d].mask;
+                const int cur_b = gg[d].b;
+                if (cur_b != acc_b) { if (acc_b >= 0) flush(acc_b); acc_b = cur_b; }
+                __syncthreads();
+                store_tile(gg[d], st[d]);
+                geometry(tile + (d + WC1_DEPTH) * t_stride, gg[d]);
+                load_tile(gg[d], st[d]);
+                __syncthreads();
+                compute(cur_mask);
+            }
+        }
+    }
+    if (acc_b >= 0) flush(acc_b);
+}
+
+// sum of the per-workgroup rows of one sample: tot[n][o] (double, zeroed by first_block_bwd_kernel).  blockIdx.z splits the rows
+// (a 16-workgroup reduce over the 7.7 MB of rows took 128 us); the slices meet in double atomics (order-dependent only in the last bits)
+__global__ __launch_bounds__(256) void first_block_reduce_kernel(const float* __restrict__ part, int rows, double* __restrict__ tot) {
+    const int n = blockIdx.y, o = blockIdx.x * 256 + threadIdx.x;
+    if (o >= FB_ROW) return;
+    const int per = (rows + gridDim.z - 1) / gridDim.z, w0 = blockIdx.z * per, w1 = min(rows, w0 + per);
+    double s = 0.0;
+    const float* p = part + (long long)n * rows * FB_ROW + o;
+    for (int w = w0; w < w1; ++w) s += (double)p[(long long)w * FB_ROW];
+    if (w1 > w0) atomicAdd(&tot[(long long)n * FB_ROW + o], s);
+}
+
+// one workgroup: group sums -> {alpha, beta, gamma} per (sample, channel) -> dW, db (convolution), dgamma, dbeta (normalisation)
+__global__ __launch_bounds__(256) void first_block_finalize_kernel(const double* __restrict__ tot, int B, long long V, FbFwd f,
+                                                                   float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                                   float* __restrict__ dw, float* __restrict__ dbias, long long s_t,
+                                                                   long long s_c, long long s_n) {
+    __shared__ double al[16][16], be[16][16], ga[16][16];       // [sample][channel]
+    const int G = f.G, cpg = 16 / G;
+    if (threadIdx.x < B * 16) {
+        const int n = threadIdx.x >> 4, c = threadIdx.x & 15, g = c / cpg, sn = f.Nb == 1 ? 0 : n;
+        const double mu = f.stats[((long long)sn * G + g) * 2], rs = f.stats[((long long)sn * G + g) * 2 + 1];
+        double A = 0.0, Bv = 0.0;                              // sums over the group (and, BatchNorm, over the samples)
+        for (int m = (f.Nb == 1 ? 0 : n); m < (f.Nb == 1 ? B : n + 1); ++m)
+            for (int j = 0; j < cpg; ++j) {
+                const int cj = g * cpg + j;
+                const double gm = f.gamma ? (double)f.gamma[cj] : 1.0;
+                const double SG = tot[(long long)m * FB_ROW + FB_SG + cj], SGZ = tot[(long long)m * FB_ROW + FB_SGZ + cj];
+                A += gm * SG;
+                Bv += gm * rs * (SGZ - mu * SG);
+            }
+        const double cnt = (double)V * cpg * (f.Nb == 1 ? B : 1), pa = A / cnt, pb = Bv / cnt;
+        const double gm = f.gamma ? (double)f.gamma[c] : 1.0;
+        al[n][c] = rs * gm;
+        be[n][c] = -rs * rs * pb;
+        ga[n][c] = rs * (rs * pb * mu - pa);
+    }
+    __syncthreads();
+    for (int o = threadIdx.x; o < 27 * 16; o += 256) {
+        const int t = o >> 4, c = o & 15;
+        double s = 0.0;
+        for (int n = 0; n < B; ++n) {
+            const double* T = tot + (long long)n * FB_ROW;
+            s += al[n][c] * T[FB_GX + o] + be[n][c] * T[FB_ZX + o] + ga[n][c] * T[FB_SX + t];
+        }
+        dw[t * s_t + c * s_n] = (float)s;                       // (one input channel: s_c unused)
+    }
+    if (threadIdx.x < 16) {
+        const int c = threadIdx.x, g = c / cpg;
+        double sb = 0.0, dg = 0.0, db = 0.0;
+        for (int n = 0; n < B; ++n) {
+            const int sn = f.Nb == 1 ? 0 : n;
+            const double mu = f.stats[((long long)sn * G + g) * 2], rs = f.stats[((long long)sn * G + g) * 2 + 1];
+            const double* T = tot + (long long)n * FB_ROW;
+            sb += al[n][c] * T[FB_SG + c] + be[n][c] * T[FB_SZ + c] + ga[n][c] * (double)V;
+            dg += rs * (T[FB_SGZ + c] - mu * T[FB_SG + c]);
+            db += T[FB_SG + c];
+        }
+        if (dbias) dbias[c] = (float)sb;
+        if (dgamma) dgamma[c] = (float)dg;
+        if (dbeta) dbeta[c] = (float)db;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // k=2 / stride-2 weight gradient on the bf16 matrix cores (down-convolutions and, with the operand roles swapped,
 // transposed convolutions):   dW[t][c_hi][c_lo] = sum_m  HI[2m + t][c_hi] * LO[m][c_lo],   t = 2x2x2 taps.
 // Same structure as wgrad_k3_bf16_kernel: natural-order LDS tiles, transposed ds_read_b64_tr_b16 fragments;
@@ -2790,6 +3091,33 @@ extern "C" size_t dycon_conv_wgrad_workspace(int mode, int B, int Di, int Hi, in
         if (n2 > need) need = n2;
     }
     return need + dycon_colsum_workspace((long long)B * Do * Ho * Wo, Cout) + 64;   // room for the un-fused bias gradient
+}
+
+// The whole backward of block_one in one pass (first_block_bwd_kernel): dW / db of the first convolution, dgamma / dbeta of the
+// normalisation that follows it.  bf16, one input channel, 16 output channels, B <= 16.
+extern "C" size_t dycon_first_block_bwd_workspace(int B, int D, int H, int W) {
+    return (size_t)B * wgrad_c1_wgs(B, D, H, W) * FB_ROW * sizeof(float) + (size_t)B * FB_ROW * sizeof(double) + 64;
+}
+extern "C" int dycon_first_block_bwd(const void* x, const void* z, const void* gy, int B, int D, int H, int W, int Nb, int G,
+                                     const float* stats, const float* gamma, const float* beta, int relu,
+                                     const float* chan_scale, float* dgamma, float* dbeta, float* dw, float* dbias, long long s_t,
+                                     long long s_c, long long s_n, float* workspace, size_t ws_bytes, dycon_stream_t stream) {
+    DYCON_REQUIRE(x && z && gy && stats && dw && workspace, "first_block_bwd: null pointer");
+    DYCON_REQUIRE(B > 0 && B <= 16 && D > 0 && H > 0 && W > 0, "first_block_bwd: bad shape (B <= 16)");
+    DYCON_REQUIRE((Nb == B || Nb == 1) && G > 0 && 16 % G == 0, "first_block_bwd: Nb must be B or 1, G must divide 16");
+    DYCON_REQUIRE(ws_bytes >= dycon_first_block_bwd_workspace(B, D, H, W), "first_block_bwd: workspace too small");
+    const int tz = cdiv(D, CL_TZ), ty = cdiv(H, CL_TY), tx = cdiv(W, CL_TX);
+    const int nTiles = B * tz * ty * tx, wgs = wgrad_c1_wgs(B, D, H, W);
+    double* tot = reinterpret_cast<double*>(workspace + (((size_t)B * wgs * FB_ROW + 1) & ~(size_t)1));
+    FbFwd f;
+    f.stats = stats; f.gamma = gamma; f.beta = beta; f.chan_scale = chan_scale; f.Nb = Nb; f.G = G; f.relu = relu;
+    first_block_bwd_kernel<<<wgs, 256, 0, stream>>>((const bf16*)x, (const bf16*)z, (const bf16*)gy, workspace, B, D, H, W, tz, ty, tx, nTiles, f, tot);
+    DYCON_LAUNCH_CHECK();
+    first_block_reduce_kernel<<<dim3(cdiv(FB_ROW, 256), B, 32), 256, 0, stream>>>(workspace, wgs, tot);
+    DYCON_LAUNCH_CHECK();
+    first_block_finalize_kernel<<<1, 256, 0, stream>>>(tot, B, (long long)D * H * W, f, dgamma, dbeta, dw, dbias, s_t, s_c, s_n);
+    DYCON_LAUNCH_CHECK();
+    return DYCON_OK;
 }
 
 template <typename TX, typename TG>

@@ -200,6 +200,7 @@ class Engine:
                                          # measured neutral for the step (+5 us per convolution against a 7 us statistics launch): off
         self._stat_parts = {}
         self.fuse_first = True           # V-Net: block_one's norm backward formed on load by the first layer's weight gradient (_first_block)
+        self.one_pass_first = True       # ... as ONE pass (dycon_first_block_bwd) instead of statistics + weight gradient
         self._deferred = {}
         self._pending_dparams = []
         self.tape = []
@@ -561,21 +562,27 @@ class Engine:
                 gy = self._take(y)
                 dg = self.g[nname + ".weight"] if gamma is not None else None
                 db = self.g[nname + ".bias"] if beta is not None else None
-                nws, ab = ops.norm_bwd_stats(z, gy, stats, Nb, V, C, G, gamma, beta, True, dg, db)
                 gw, gb = self.g[cname + ".weight"], self.g[cname + ".bias"]
-                wws = self._wws.get(cname + "#nb")
-                if wws is None:
-                    wws = self._wws[cname + "#nb"] = ops._ws(ops.query("dycon_conv1_wgrad_normbwd_workspace", *x.shape[:4]), x)
-                if self.wgrad_stream is not None:
-                    ev, cs, ws_ = torch.cuda.Event(), ops.cur_stream(), self.wgrad_stream
-                    ops.rec(lambda: (ev.record(cs), ws_.wait_event(ev)))
-                    with ops.on_stream(self.wgrad_stream, light=True):
-                        self._flush_dparams()
-                        ops.conv1_wgrad_normbwd(x, z, gy, stats, ab, Nb, G, gw, gb, gamma, beta, True, None, ws=wws)
-                    for t in (gy, nws):
-                        t.record_stream(self.wgrad_stream)
+                if self.one_pass_first:       # everything in ONE pass over (x, z, gy), on the chain (it is the exposed tail of the backward)
+                    wws = self._wws.get(cname + "#fb")
+                    if wws is None:
+                        wws = self._wws[cname + "#fb"] = ops._ws(ops.query("dycon_first_block_bwd_workspace", *x.shape[:4]), x)
+                    ops.first_block_bwd(x, z, gy, stats, Nb, G, gw, gb, gamma, beta, True, dg, db, None, ws=wws)
                 else:
-                    ops.conv1_wgrad_normbwd(x, z, gy, stats, ab, Nb, G, gw, gb, gamma, beta, True, None, ws=wws)
+                    nws, ab = ops.norm_bwd_stats(z, gy, stats, Nb, V, C, G, gamma, beta, True, dg, db)
+                    wws = self._wws.get(cname + "#nb")
+                    if wws is None:
+                        wws = self._wws[cname + "#nb"] = ops._ws(ops.query("dycon_conv1_wgrad_normbwd_workspace", *x.shape[:4]), x)
+                    if self.wgrad_stream is not None:
+                        ev, cs, ws_ = torch.cuda.Event(), ops.cur_stream(), self.wgrad_stream
+                        ops.rec(lambda: (ev.record(cs), ws_.wait_event(ev)))
+                        with ops.on_stream(self.wgrad_stream, light=True):
+                            self._flush_dparams()
+                            ops.conv1_wgrad_normbwd(x, z, gy, stats, ab, Nb, G, gw, gb, gamma, beta, True, None, ws=wws)
+                        for t in (gy, nws):
+                            t.record_stream(self.wgrad_stream)
+                    else:
+                        ops.conv1_wgrad_normbwd(x, z, gy, stats, ab, Nb, G, gw, gb, gamma, beta, True, None, ws=wws)
                 if self.on_param_grads is not None:
                     if gamma is not None:
                         self.on_param_grads(nname + ".weight")

@@ -437,6 +437,17 @@ def norm_bwd_stats(src, gy, stats, Nb, V, C, G, gamma=None, beta=None, relu=True
     return ws, ws[off:off + Nb * G * 2]
 
 
+def first_block_bwd(x, z, gy, stats, Nb, G, dw, dbias, gamma=None, beta=None, relu=True, dgamma=None, dbeta=None, chan_scale=None, ws=None):
+    """backward of (conv 1 -> 16, k=3) + norm + ReLU in one pass over (x, z, gy): writes dw, dbias, dgamma, dbeta"""
+    B, D, H, W, _ = x.shape
+    if ws is None:
+        ws = _ws(query("dycon_first_block_bwd_workspace", B, D, H, W), x)
+    with _Region("wgrad_k3_bf16", (x.numel() + z.numel() + gy.numel()) * 2 + 27 * 16 * 4, 6 * (gy.numel() // 16) * 27 * 16):
+        call("dycon_first_block_bwd", _p(x), _p(z), _p(gy), B, D, H, W, Nb, G, _p(stats), _p(gamma), _p(beta), int(relu),
+             _p(chan_scale), _p(dgamma), _p(dbeta), _p(dw), _p(dbias), 1, 27, 27, _p(ws), ws.numel() * 4, _s())
+    return dw
+
+
 def conv1_wgrad_normbwd(x, z, gy, stats, ab, Nb, G, dw, dbias, gamma=None, beta=None, relu=True, chan_scale=None, ws=None):
     """weight + bias gradient of the first (1 -> 16, k=3, bf16) convolution with the following normalisation's data gradient formed on load"""
     B, D, H, W, _ = x.shape

@@ -71,6 +71,7 @@ class TrainConfig:
     overlap_features: bool = True       # feature branch (projection head, embeddings, FeCL forward + backward) on its own stream
     split_repack: bool = True           # the student's weight repack off the head of the dependent chain (Engine.repack)
     conv_stats: bool = False            # norm statistics taken by the producing convolution where it is persistent (measured neutral: off)
+    one_pass_first: bool = True         # block_one's backward as one pass over (x, z, gy) (Engine.one_pass_first)
     fuse_first: bool = True             # V-Net: block_one's norm backward inside the first layer's weight gradient (Engine._first_block)
     fuse_head: bool = True              # V-Net: out_conv fused into block_nine's normalisation passes (Engine._norm_head)
     fuse_finish: bool = False           # small levels: split-K finish of a convolution done by the one-launch norm that follows (Engine.fuse_finish)
@@ -142,6 +143,7 @@ class DyconTrainer:
         self.s_eng.fuse_finish = self.t_eng.fuse_finish = cfg.fuse_finish
         self.s_eng.fuse_head = self.t_eng.fuse_head = cfg.fuse_head
         self.s_eng.fuse_first = self.t_eng.fuse_first = cfg.fuse_first
+        self.s_eng.one_pass_first = self.t_eng.one_pass_first = cfg.one_pass_first
         self.s_eng.conv_stats = self.t_eng.conv_stats = cfg.conv_stats
         # accumulator form of the norms (engine.use_acc; measured slower, off by default): one arena of zeroed doubles per step,
         # shared by both nets and cleared by ONE launch at the start of the step, before the teacher stream forks

@@ -201,6 +201,16 @@ size_t dycon_norm_bwd_ab_offset(int Nb, long long V, int C);
 int dycon_norm_bwd_stats(const void* src, const void* gy, int dtype, int Nb, long long V, int C, int G, const float* stats,
                          const float* gamma, const float* beta, int relu, const float* chan_scale, float* dgamma,
                          float* dbeta, float* workspace, size_t ws_bytes, dycon_stream_t stream);
+/* The whole backward of block_one in ONE pass over (x, z, gy): the normalisation's data gradient is affine in (g', z) with
+ * coefficients that depend on group sums the same pass takes, so the first convolution's weight gradient is a combination of three tap
+ * correlations (sum g' x, sum z x, sum x) that do not depend on them (csrc/conv.hip, first_block_bwd_kernel).  Writes dw / dbias of the
+ * convolution (layout as dycon_conv_wgrad) and dgamma / dbeta of the normalisation; no bf16 rounding of the data gradient enters dw.
+ * Replaces dycon_norm_bwd_stats + dycon_conv1_wgrad_normbwd (the inputs are read once instead of twice). */
+size_t dycon_first_block_bwd_workspace(int B, int D, int H, int W);
+int dycon_first_block_bwd(const void* x, const void* z, const void* gy, int B, int D, int H, int W, int Nb, int G,
+                          const float* stats, const float* gamma, const float* beta, int relu, const float* chan_scale,
+                          float* dgamma, float* dbeta, float* dw, float* dbias, long long s_t, long long s_c, long long s_n,
+                          float* workspace, size_t ws_bytes, dycon_stream_t stream);
 size_t dycon_conv1_wgrad_normbwd_workspace(int B, int D, int H, int W);
 int dycon_conv1_wgrad_normbwd(const void* x, const void* z, const void* gy, int B, int D, int H, int W, int Nb, int G,
                               const float* stats, const float* gamma, const float* beta, int relu, const float* chan_scale,

@@ -611,3 +611,50 @@ def test_first_layer_wgrad_with_norm_backward_on_load(kind, sp):
     # rounding noise, so the bound is a fraction of sqrt(B*V) bf16 half-steps of rms(gz), not a relative one
     noise = 0.05 * (B * V) ** 0.5 * 2.0 ** -8 * float(gz.float().pow(2).mean().sqrt())
     assert float((gb - gb_ref).abs().max()) <= 2e-3 * sb + noise, (float((gb - gb_ref).abs().max()), sb, noise)
+
+
+@pytest.mark.parametrize("kind", ["gn", "in", "bn"])
+@pytest.mark.parametrize("sp", [(24, 20, 28), (10, 9, 13)])
+def test_first_block_backward_in_one_pass(kind, sp):
+    """dycon_first_block_bwd (block_one's whole backward as ONE pass: three tap correlations + per-channel sums, combined afterwards)
+    against torch autograd in DOUBLE on the same bf16 inputs: no rounding of the data gradient enters dW, so the bound is fp32
+    accumulation, not bf16."""
+    rng = np.random.default_rng(zlib.crc32(repr(("fb", kind, sp)).encode()))
+    B, C = 3, 16
+    V = sp[0] * sp[1] * sp[2]
+    xh = torch.from_numpy(rng.standard_normal((B, 1) + sp).astype(np.float32)).bfloat16()
+    zh = torch.from_numpy(rng.standard_normal((B, C) + sp).astype(np.float32) * 1.3 + 0.2).bfloat16()
+    gh = torch.from_numpy(rng.standard_normal((B, C) + sp).astype(np.float32)).bfloat16()
+    affine = kind != "in"
+    gamma = torch.from_numpy(rng.standard_normal(C).astype(np.float32) * 0.5 + 1.0) if affine else None
+    beta = torch.from_numpy(rng.standard_normal(C).astype(np.float32) * 0.3) if affine else None
+    # ---- reference: autograd in double
+    zd = zh.double().requires_grad_(True)
+    gd, bd = (gamma.double().requires_grad_(True), beta.double().requires_grad_(True)) if affine else (None, None)
+    if kind == "gn":
+        nd_ = F.group_norm(zd, 16, gd, bd, 1e-5)
+    elif kind == "in":
+        nd_ = F.instance_norm(zd, eps=1e-5)
+    else:
+        nd_ = F.batch_norm(zd, None, None, gd, bd, True, 0.1, 1e-5)
+    F.relu(nd_).backward(gh.double())
+    gz = zd.grad
+    dw_ref = torch.nn.grad.conv3d_weight(xh.double(), (C, 1, 3, 3, 3), gz, padding=1)
+    db_ref = gz.sum((0, 2, 3, 4))
+    # ---- one pass on the GPU
+    x, z, gy = nd(xh.float(), torch.bfloat16), nd(zh.float(), torch.bfloat16), nd(gh.float(), torch.bfloat16)
+    Nb, G, Vn = (1, C, B * V) if kind == "bn" else (B, 16, V)
+    gam, bet = (gamma.to(DEV), beta.to(DEV)) if affine else (None, None)
+    _, stats = ops.norm_fwd(z, Nb, Vn, C, G, gam, bet, True)
+    gw, gb = torch.empty(C, 1, 3, 3, 3, device=DEV), torch.empty(C, device=DEV)
+    dg, dbt = (torch.empty(C, device=DEV), torch.empty(C, device=DEV)) if affine else (None, None)
+    ops.first_block_bwd(x, z, gy, stats, Nb, G, gw, gb, gam, bet, True, dg, dbt)
+    torch.cuda.synchronize()
+    sw = float(dw_ref.abs().max())
+    assert float((gw.cpu().double() - dw_ref).abs().max()) <= 2e-4 * sw, (float((gw.cpu().double() - dw_ref).abs().max()), sw)
+    # sum(gz) is ~0 analytically: compare on the scale of the terms that cancel in it
+    scale_b = float(gz.abs().sum((0, 2, 3, 4)).max())
+    assert float((gb.cpu().double() - db_ref).abs().max()) <= 1e-5 * scale_b
+    if affine:
+        close(dg, gd.grad.float(), 2e-4, 2e-4 * float(gd.grad.abs().max()), "dgamma")
+        close(dbt, bd.grad.float(), 2e-4, 2e-4 * float(bd.grad.abs().max()), "dbeta")
