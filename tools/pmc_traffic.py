@@ -16,14 +16,15 @@ steps = int(sys.argv[4]) if len(sys.argv) > 4 else 3
 # kernel-name substring -> bench.py region (ops._Region names)
 REGIONS = [("head_1x1_fwd_kernel", "conv_direct"), ("head_1x1_bwd_kernel", "conv_direct"), ("grad_1x1_skinny_kernel", "conv_direct"),
            ("conv_direct_kernel", "conv_direct"), ("conv_k3_p16_kernel", "conv_k3_p16"), ("conv_k3_c1_kernel", "conv_k3_c1"), ("conv_k3_lds_kernel", "conv_k3_lds"), ("conv_k3_p32_kernel", "conv_k3_lds"),
-           ("conv_k3_tile_kernel", "conv_k3_tile"), ("wgrad_k3_bf16_kernel", "wgrad_k3_bf16"), ("wgrad_k3_c1_kernel", "wgrad_k3_bf16"), ("wgrad_1x1_bf16_kernel", "conv_wgrad"), ("wgrad_k2s2_bf16_kernel", "conv_wgrad"),
+           ("conv_k3_tile_kernel", "conv_k3_tile"), ("wgrad_k3_bf16_kernel", "wgrad_k3_bf16"), ("wgrad_k3_c1_kernel", "wgrad_k3_bf16"), ("first_block_bwd_kernel", "wgrad_k3_bf16"), ("wgrad_1x1_bf16_kernel", "conv_wgrad"), ("wgrad_k2s2_bf16_kernel", "conv_wgrad"),
            ("conv_wgrad_kernel", "conv_wgrad"), ("conv_gemm_kernel", "conv_gemm"), ("norm_apply_kernel", "norm_fwd"), ("norm_apply_head_kernel", "norm_fwd"), ("norm_head_partial_kernel", "norm_bwd"),
            ("norm_head_bwd_apply_kernel", "norm_bwd"),
            ("norm_partial_kernel<__hip_bfloat16, 0>", "norm_fwd"), ("norm_fused_fwd_kernel", "norm_fwd"),
            ("norm_partial_kernel<__hip_bfloat16, 1>", "norm_bwd"), ("norm_bwd_apply_kernel", "norm_bwd"), ("norm_fused_bwd_kernel", "norm_bwd")]
 # per-step accounting: the helper launches of a family
 STEP_EXTRA = [("norm_finalize_stats_kernel", "norm_fwd"), ("norm_finalize_bwd_kernel", "norm_bwd"), ("norm_sum_dparams_kernel", "norm_bwd"), ("norm_head_finalize_kernel", "norm_bwd"),
-              ("splitk_finish_kernel", "conv_k3_tile+conv_gemm_splitk"), ("reduce_partials", "wgrad_k3_bf16+conv_wgrad"), ("colsum_kernel", "colsum")]
+              ("splitk_finish_kernel", "conv_k3_tile+conv_gemm_splitk"), ("reduce_partials", "wgrad_k3_bf16+conv_wgrad"), ("first_block_reduce_kernel", "wgrad_k3_bf16+conv_wgrad"),
+              ("first_block_finalize_kernel", "wgrad_k3_bf16+conv_wgrad"), ("colsum_kernel", "colsum")]
 
 
 def load(kind):
