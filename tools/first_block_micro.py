@@ -1,3 +1,5 @@
+"""block_one's backward at the bench shape (B = 4, 96^3, bf16): norm statistics + weight gradient with the norm backward on load (two launches' worth
+of passes) against the one-pass form (dycon_first_block_bwd)."""
 import sys, torch
 sys.path.insert(0, __file__.rsplit("/", 2)[0])
 from dycon_paper_replication_amd import ops
