@@ -349,6 +349,7 @@ class DyconTrainer:
             t_drop = DropoutSpec("philox", seed=seed, offset=(2 * it + 1) << 42) if c.teacher_mode == "train" else DropoutSpec("off")
 
         self._mark("step_begin")
+        ops.rec(lambda: self.sumsq.zero_())          # (its first use is mid-backward at the earliest)
         if self.acc_arena is not None:
             arena = self.acc_arena
             ops.rec(lambda: arena.zero_())
@@ -457,7 +458,6 @@ class DyconTrainer:
                 self._pending = []
             ops.rec(join)
         self._mark("bwd_joined")
-        ops.rec(lambda: self.sumsq.zero_())
         ops.sumsq(self.flat_g[: self.n_sgd], self.sumsq)
         alpha = min(1 - 1 / (it + 1), c.ema_decay)
         ops.sgd_ema(self.flat_p, self.flat_g, self.flat_m, self.flat_t, self.n_sgd, self.sumsq, c.max_grad_norm, 1.0 / world,
