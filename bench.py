@@ -83,6 +83,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--strict", action="store_true", help="exit non-zero when the per-kernel table fails its self-check")
+    ap.add_argument("--cfg", default="", help="diagnostics: TrainConfig overrides, e.g. overlap_wgrad=False,overlap_teacher=False")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -111,8 +112,9 @@ def main():
     from dycon_paper_replication_amd.trainer import DyconTrainer, TrainConfig
 
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    extra = {k: eval(v) for k, v in (kv.split("=") for kv in args.cfg.split(",") if kv)}      # diagnostics only (tools/)
     cfg = TrainConfig(model=args.model, batch_size=args.batch, labeled_bs=args.labeled, dtype=dtype, seed=1337,
-                      feature_scaler=args.feature_scaler)
+                      feature_scaler=args.feature_scaler, **extra)
     tr = DyconTrainer(cfg, dev, process_group=pg)
     patch = tuple(args.patch)
     vol, lab, _ = make_batch(1337 + rank, args.batch, patch)

@@ -157,6 +157,62 @@ class Recorder:
 
 RECORDER = None
 
+# ---------------------------------------------------------------- HIP runtime: events of the step's fork / join structure
+# torch.cuda.Event() is created with hipEventDisableTiming only, so every record carries a SYSTEM-scope release (cache write-back
+# and invalidate, hip_runtime_api.h: hipEventDisableSystemFence).  The step's ~50 cross-stream dependencies are device-local
+# (producer and consumer kernels on the same GPU): their events are created here with the fence narrowed, and recorded / waited
+# through ctypes (also cheaper on the host than the torch objects).  DYCON_EVENT_FLAGS = default | nofence | device (diagnostic).
+HIP_EVENT_DISABLE_TIMING, HIP_EVENT_NO_SYSTEM_FENCE, HIP_EVENT_RELEASE_TO_DEVICE = 0x2, 0x20000000, 0x40000000
+_EVENT_FLAGS = {"default": HIP_EVENT_DISABLE_TIMING, "nofence": HIP_EVENT_DISABLE_TIMING | HIP_EVENT_NO_SYSTEM_FENCE,
+                "device": HIP_EVENT_DISABLE_TIMING | HIP_EVENT_RELEASE_TO_DEVICE,
+                "device_nofence": HIP_EVENT_DISABLE_TIMING | HIP_EVENT_RELEASE_TO_DEVICE | HIP_EVENT_NO_SYSTEM_FENCE}
+EVENT_MODE = os.environ.get("DYCON_EVENT_FLAGS", "device")
+_hip = None
+
+
+def hip():
+    """libamdhip64 (the runtime torch already loaded) with the four event entry points prototyped"""
+    global _hip
+    if _hip is None:
+        h = C.CDLL("libamdhip64.so")
+        h.hipEventCreateWithFlags.restype, h.hipEventCreateWithFlags.argtypes = I, [C.POINTER(P), C.c_uint]
+        h.hipEventRecord.restype, h.hipEventRecord.argtypes = I, [P, P]
+        h.hipStreamWaitEvent.restype, h.hipStreamWaitEvent.argtypes = I, [P, P, C.c_uint]
+        h.hipEventDestroy.restype, h.hipEventDestroy.argtypes = I, [P]
+        _hip = h
+    return _hip
+
+
+class HipEvent:
+    """A device-local HIP event (no timing, narrowed fence: see above)."""
+    __slots__ = ("h",)
+
+    def __init__(self):
+        ev = P()
+        rc = hip().hipEventCreateWithFlags(C.byref(ev), _EVENT_FLAGS[EVENT_MODE])
+        if rc:
+            raise DyconLibraryError(f"hipEventCreateWithFlags failed ({rc})")
+        self.h = ev.value
+
+    def __del__(self):
+        try:
+            if self.h and _hip is not None:
+                _hip.hipEventDestroy(self.h)
+        except Exception:       # interpreter shutdown
+            pass
+
+
+def hip_call(name, *args, keep=None):
+    """An event / stream entry point of the HIP runtime, logged like a C-ABI call while a step is being recorded."""
+    fn = getattr(hip(), name)
+    rc = fn(*args)
+    if rc:
+        raise DyconLibraryError(f"{name} failed ({rc})")
+    if RECORDER is not None:
+        RECORDER.entries.append([fn, list(args), name])
+        if keep is not None:
+            RECORDER.keep.append(keep)
+
 
 def call(name, *args):
     """Invoke an int-returning entry point; raise with dycon_last_error() on failure."""

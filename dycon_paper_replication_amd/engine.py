@@ -11,6 +11,7 @@ always fp32.  Parameters stay in the reference's torch layouts/names (state_dict
 """
 from __future__ import annotations
 
+import os
 from collections import OrderedDict
 from typing import Dict, Optional
 
@@ -21,8 +22,10 @@ from ._lib import CONV_1X1, CONV_K2S2, CONV_K3
 
 UNET_FILTERS = (16, 32, 64, 128, 256)
 VNET_NORMS = ("groupnorm", "instancenorm", "batchnorm", "none")      # VNet.py:17-24
-ABLATE_N = [0]
-ABLATE = set()     # tools/ablate.py only (timing experiments with parts of the step switched off); always empty otherwise
+# tools/ablate.py only (timing experiments with parts of the step switched off, each case in a fresh process): read ONCE at import,
+# immutable afterwards -- nothing in a training or test process can switch a part of the step off
+ABLATE = frozenset(a for a in os.environ.get("DYCON_ABLATE", "").split(",") if a)
+ABLATE_N = int(os.environ.get("DYCON_ABLATE_N", "0"))
 
 
 # --------------------------------------------------------------------------------------
@@ -268,11 +271,11 @@ class Engine:
         if split and len(self._jobs_dev) == 2:
             (d0, n0, b0), (d1, n1, b1) = self._jobs_dev
             ops.pack_batch(d0, n0, b0)
-            ev0, ev1, cur = torch.cuda.Event(), torch.cuda.Event(), ops.cur_stream()
-            ops.rec(lambda: (ev0.record(cur), helper.wait_event(ev0)))       # the update that changed the parameters precedes this point
+            ops.fork(ops.cur_stream(), helper)       # the update that changed the parameters precedes this point
             with ops.on_stream(helper, light=True):
                 ops.pack_batch(d1, n1, b1)
-                ops.rec(lambda: ev1.record(helper))
+                ev1 = ops.Event()
+                ev1.record(helper)
             self._pack_event = ev1
         else:
             for d, n, b in self._jobs_dev:
@@ -286,8 +289,7 @@ class Engine:
         """the packs launched on the helper stream by repack(early=..., helper=...) are needed from here on"""
         ev = getattr(self, "_pack_event", None)
         if ev is not None:
-            cur = ops.cur_stream()
-            ops.rec(lambda: cur.wait_event(ev))
+            ev.wait(ops.cur_stream())
             self._pack_event = None
 
     # ---------------------------------------------------------------- gradient bookkeeping
@@ -300,7 +302,7 @@ class Engine:
         cur = ops.cur_stream()
         src = self.Gs.get(key)
         if src is not None and src != cur:
-            ops.rec(lambda: cur.wait_stream(src))
+            ops.fork(src, cur)
             g.record_stream(cur)
 
     def _take(self, t):
@@ -395,8 +397,7 @@ class Engine:
                 if "wgrad" in ABLATE:
                     pass
                 elif "wgrad_events_only" in ABLATE and self.wgrad_stream is not None:      # the fork, without the kernels
-                    ev, cs, ws_ = torch.cuda.Event(), ops.cur_stream(), self.wgrad_stream
-                    ops.rec(lambda: (ev.record(cs), ws_.wait_event(ev)))
+                    ops.fork(ops.cur_stream(), self.wgrad_stream)
                 elif "wgrad_no_events" in ABLATE and self.wgrad_stream is not None:        # the kernels, without the fork (a race: timing only)
                     with ops.on_stream(self.wgrad_stream, light=True):
                         wgrad(gy)
@@ -404,8 +405,7 @@ class Engine:
                     # The weight gradient only feeds the optimiser; the data gradient is the critical chain.  Enqueue the former on a
                     # second HIP stream (behind an event that marks gy ready) so the small-level wgrad / reduce launches fill the
                     # CUs the latency-bound dgrad / norm-backward kernels leave idle.  backward() joins the streams at the end.
-                    ev, cs, ws_ = torch.cuda.Event(), ops.cur_stream(), self.wgrad_stream
-                    ops.rec(lambda: (ev.record(cs), ws_.wait_event(ev)))
+                    ops.fork(ops.cur_stream(), self.wgrad_stream)
                     with ops.on_stream(self.wgrad_stream, light=True):
                         self._flush_dparams()
                         wgrad(gy)
@@ -574,8 +574,7 @@ class Engine:
                     if wws is None:
                         wws = self._wws[cname + "#nb"] = ops._ws(ops.query("dycon_conv1_wgrad_normbwd_workspace", *x.shape[:4]), x)
                     if self.wgrad_stream is not None:
-                        ev, cs, ws_ = torch.cuda.Event(), ops.cur_stream(), self.wgrad_stream
-                        ops.rec(lambda: (ev.record(cs), ws_.wait_event(ev)))
+                        ops.fork(ops.cur_stream(), self.wgrad_stream)
                         with ops.on_stream(self.wgrad_stream, light=True):
                             self._flush_dparams()
                             ops.conv1_wgrad_normbwd(x, z, gy, stats, ab, Nb, G, gw, gb, gamma, beta, True, None, ws=wws)
@@ -624,8 +623,7 @@ class Engine:
                 gz, pend = ops.norm_head_bwd(z, gl, stats, Nb, V, G, hw, gamma, beta, True, dg, db, chan_scale)
                 gw, gb = self.g[head + ".weight"], self.g[head + ".bias"]
                 if self.wgrad_stream is not None:      # the head's 2 x 16 weight gradient: a sum of per-chunk partials, off the chain
-                    ev, cs, ws_ = torch.cuda.Event(), ops.cur_stream(), self.wgrad_stream
-                    ops.rec(lambda: (ev.record(cs), ws_.wait_event(ev)))
+                    ops.fork(ops.cur_stream(), self.wgrad_stream)
                     with ops.on_stream(self.wgrad_stream, light=True):
                         ops.norm_head_dparams(pend, gw, gb)
                     pend[0].record_stream(self.wgrad_stream)
@@ -689,8 +687,8 @@ class Engine:
     def _mark_ready(self):
         if self.feat_stream is None:
             return None
-        ev, cs = torch.cuda.Event(), ops.cur_stream()
-        ops.rec(lambda: ev.record(cs))
+        ev = ops.Event()
+        ev.record(ops.cur_stream())
         return ev
 
     def _head_branch(self, center, ready, training):
@@ -701,8 +699,7 @@ class Engine:
             feats = self._head(center, training)
         else:
             with ops.on_stream(self.feat_stream):
-                fs = self.feat_stream
-                ops.rec(lambda: fs.wait_event(ready))
+                ready.wait(self.feat_stream)
                 feats = self._head(center, training)
             center.record_stream(self.feat_stream)
         self._head_range = (h0, len(self.tape))
@@ -860,8 +857,7 @@ class Engine:
                 self.tape[i]()
         cs = ops.cur_stream()
         if self._pending_dparams:                             # (a norm whose convolution does not run its weight gradient on the side stream)
-            ev, ws_ = torch.cuda.Event(), self.wgrad_stream
-            ops.rec(lambda: (ev.record(cs), ws_.wait_event(ev)))
+            ops.fork(cs, self.wgrad_stream)
             with ops.on_stream(self.wgrad_stream, light=True):
                 self._flush_dparams()
         if self.mark is not None:                             # tools/timeline.py
@@ -871,9 +867,7 @@ class Engine:
             if self.wgrad_stream is not None:
                 self.mark("wgrad_end", self.wgrad_stream)
         if self.feat_stream is not None:
-            fs = self.feat_stream
-            ops.rec(lambda: cs.wait_stream(fs))
+            ops.fork(self.feat_stream, cs)
         if self.wgrad_stream is not None:
-            ws_ = self.wgrad_stream
-            ops.rec(lambda: cs.wait_stream(ws_))              # all parameter gradients are complete behind this point
+            ops.fork(self.wgrad_stream, cs)                   # all parameter gradients are complete behind this point
         self.tape, self.G = [], {}

@@ -83,6 +83,31 @@ def rec(thunk):
         _lib.RECORDER.entries.append(thunk)
 
 
+# ------------------------------------------------------------------ cross-stream dependencies of the step
+class Event:
+    """A device-local dependency marker (HIP event without timing and with the fence narrowed to the device, _lib.HipEvent):
+    record(stream) / wait(stream) enqueue through ctypes and are part of the recorded step."""
+    __slots__ = ("ev",)
+
+    def __init__(self):
+        self.ev = _lib.HipEvent()
+
+    def record(self, stream):
+        _lib.hip_call("hipEventRecord", self.ev.h, stream.cuda_stream, keep=self.ev)
+
+    def wait(self, stream):
+        """`stream` waits for the work captured by the last record()"""
+        _lib.hip_call("hipStreamWaitEvent", stream.cuda_stream, self.ev.h, 0, keep=self.ev)
+
+
+def fork(src, dst):
+    """`dst` waits for everything enqueued on `src` so far (torch: dst.wait_stream(src)); returns the event"""
+    ev = Event()
+    ev.record(src)
+    ev.wait(dst)
+    return ev
+
+
 # ------------------------------------------------------------------ optional per-kernel timing (bench.py)
 class KernelProfiler:
     """HIP-event timing of individual entry points on the launch stream (ops.cur_stream()), with the

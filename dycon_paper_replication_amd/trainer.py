@@ -25,7 +25,7 @@ from typing import Dict, Optional
 import torch
 
 from . import _lib, ops
-from .engine import DropoutSpec, Engine, param_spec, projection_buffers
+from .engine import ABLATE, ABLATE_N, DropoutSpec, Engine, param_spec, projection_buffers
 from .networks.net_factory_3d import net_factory_3d
 from .utils import ramps
 from .utils.dycon_losses import adaptive_beta, sigmoid_rampup
@@ -368,13 +368,12 @@ class DyconTrainer:
         # small, launch-latency-bound kernels of the deep levels (6^3, 12^3: 50-100 workgroups on 256 CUs) of the two nets overlap.
         t_train = c.teacher_mode == "train"
         main = self._main = ops.cur_stream()
-        from .engine import ABLATE, ABLATE_N
         if "teacher" in ABLATE:      # tools/ablate.py (timing experiment only)
             s_logits, s_feat, _ = self.s_eng.forward(x, training=True, record=True, dropout=s_drop, update_bn=True)
             t_logits, t_feat = s_logits, s_feat
         elif c.overlap_teacher:
             side = self.side
-            ops.rec(lambda: side.wait_stream(main))
+            ops.fork(main, side)
             with ops.on_stream(self.side):
                 self.t_eng.repack()  # the teacher's packs belong to its stream (the EMA update that changed them precedes the fork)
                 t_logits, t_feat, _ = self.t_eng.forward(x_t, training=t_train, record=False, dropout=t_drop, update_bn=t_train)
@@ -385,7 +384,7 @@ class DyconTrainer:
         if "teacher" in ABLATE:
             pass
         elif c.overlap_teacher:
-            ops.rec(lambda: main.wait_stream(side))
+            ops.fork(side, main)
             t_logits.record_stream(main)
             t_feat.record_stream(main)
         else:
@@ -395,7 +394,7 @@ class DyconTrainer:
             if not hasattr(self, "_xs"):
                 self._xs, self._xbuf = torch.cuda.Stream(device=self.device), torch.zeros(8, device=self.device)
             with ops.on_stream(self._xs, light=True):
-                for _ in range(ABLATE_N[0]):
+                for _ in range(ABLATE_N):
                     ops.set_scalars(self._xbuf, [0.0])
         self._mark("student_fwd_end")
         # ---- losses (:308-357)
@@ -406,7 +405,7 @@ class DyconTrainer:
         with fctx():
             if self.feat is not None:                     # teacher features (the student's head was enqueued on self.feat)
                 feat, src = self.feat, (self.side if c.overlap_teacher else main)
-                ops.rec(lambda: feat.wait_stream(src))
+                ops.fork(src, feat)
                 t_feat.record_stream(self.feat)
             s_emb, s_nrm = ops.l2norm_fwd(s_feat.reshape(B, -1, s_feat.shape[-1]))          # :316-319
             t_emb, _ = ops.l2norm_fwd(t_feat.reshape(B, -1, t_feat.shape[-1]))              # :321-323
@@ -417,7 +416,7 @@ class DyconTrainer:
             f_loss, fst = ops.fecl_fwd(*fargs, 1.0)
             self._mark("fecl_fwd_end")
         if self.feat is not None:
-            ops.rec(lambda: main.wait_stream(feat))       # the scalar loss (and the DDP exchange below) needs the FeCL sums
+            ops.fork(feat, main)       # the scalar loss (and the DDP exchange below) needs the FeCL sums
             for t in (t_feat, f_loss, fst.out, mask):
                 t.record_stream(main)
         gw = 1
@@ -443,7 +442,7 @@ class DyconTrainer:
         self._mark("loss_end")
         g_logits = ops.seg_losses_bwd(s_logits, t_logits, label, LB, beta, sums, self.coef, cons_kind, fast=self._fast_math)
         if self.feat is not None:
-            ops.rec(lambda: feat.wait_stream(main))       # coef (and, with DDP, the all-reduced FeCL sums)
+            ops.fork(main, feat)       # coef (and, with DDP, the all-reduced FeCL sums)
         with fctx():
             g_emb = ops.fecl_bwd(*fargs, float(gw), fst, self.coef[5:6])
             g_feat = ops.l2norm_bwd(s_emb, s_nrm, g_emb).reshape(s_feat.shape)

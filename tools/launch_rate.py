@@ -10,12 +10,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CHILD = r'''
 import sys, time, torch
 sys.path.insert(0, %r)
-from dycon_paper_replication_amd import engine
 from dycon_paper_replication_amd.synthetic import make_batch
 from dycon_paper_replication_amd.trainer import DyconTrainer, TrainConfig
 n = int(sys.argv[1])
-if n:
-    engine.ABLATE.add("extra_launches"); engine.ABLATE_N[0] = n
 dev = torch.device("cuda:0")
 vol, lab, _ = make_batch(1337, 4, (96, 96, 96))
 vol, lab = vol.to(dev), lab.to(torch.uint8).to(dev)
@@ -27,4 +24,5 @@ torch.cuda.synchronize()
 print("%%d extra launches per step: %%.3f ms/step" %% (n, (time.perf_counter() - t0) * 10))
 ''' % ROOT
 for n in (0, 50, 100, 200, 0):
-    subprocess.run([sys.executable, "-c", CHILD, str(n)], check=True)
+    env = dict(os.environ, DYCON_ABLATE="extra_launches" if n else "", DYCON_ABLATE_N=str(n))      # read once at import (engine.ABLATE)
+    subprocess.run([sys.executable, "-c", CHILD, str(n)], check=True, env=env)
