@@ -52,9 +52,8 @@ class RandomRot(object):
 
 
 class ThreeStreamBatchSampler(Sampler):
-    """primary + secondary + primary batches: a second group of labelled indices follows the unlabelled ones (:280-308).  One epoch
-    is one pass over the primary permutation, consumed two groups per batch, so its length is the number of batches the primary
-    indices last for -- the reference's `__len__` (primary // primary_batch_size) is an upper bound that its zip() cuts short."""
+    """[primary | secondary | primary] batches (:280-308).  As the reference behaves: the first and the third group of a batch are the
+    SAME primary indices (see __iter__), an epoch is one pass over the primary permutation = len(primary) // primary_batch_size batches."""
 
     def __init__(self, primary_indices, secondary_indices, batch_size, secondary_batch_size):
         self.primary_indices, self.secondary_indices = primary_indices, secondary_indices
@@ -67,6 +66,10 @@ class ThreeStreamBatchSampler(Sampler):
         return len(self.primary_indices) // self.primary_batch_size
 
     def __iter__(self):
+        # The reference zips grouper(primary_iter), grouper(secondary_iter), grouper(primary_iter) where primary_iter is an ndarray
+        # (np.random.permutation), not an iterator: each grouper() takes its OWN iter() of it, so the first and the third group of a
+        # batch are the same indices -- every batch is [primary group | secondary group | the same primary group], and an epoch has
+        # len(primary) // primary_batch_size batches (dataloaders/isles22.py:296-305, 310-311, 321-325).  Reproduced as it is.
         labelled = list(np.random.permutation(self.primary_indices))
 
         def unlabelled_forever():
@@ -75,10 +78,7 @@ class ThreeStreamBatchSampler(Sampler):
 
         stream = unlabelled_forever()
         nl, nu = self.primary_batch_size, self.secondary_batch_size
-        pos = 0
-        while pos + 2 * nl <= len(labelled):     # zip() of two groupers over ONE iterator: each batch takes two primary groups
+        for pos in range(0, len(labelled) - nl + 1, nl):
             head = tuple(labelled[pos:pos + nl])
             mid = tuple(next(stream) for _ in range(nu))
-            tail = tuple(labelled[pos + nl:pos + 2 * nl])
-            pos += 2 * nl
-            yield head + mid + tail
+            yield head + mid + head

@@ -378,16 +378,17 @@ class Engine:
                 gw, gb = self.g[name + ".weight"], self.g[name + ".bias"]
                 # workspaces of the weight-gradient launches are kept per layer: on the side stream nothing may be allocated
                 # (the section only redirects this module's launches, torch's current stream -- and allocator pool -- stays put)
-                ws = self._wws.get(name)
+                wkey = (name, tuple(x.shape[:4]))       # (one Engine serves training patches and sliding-window batches)
+                ws = self._wws.get(wkey)
                 if kind == "deconv":   # dW[ci][co][t] = sum_m x[m,ci] * gy[2m+t,co]   (roles of x and gy swapped)
                     if ws is None:
-                        ws = self._wws[name] = (ops._ws(ops.query("dycon_colsum_workspace", gy.numel() // gy.shape[-1], gy.shape[-1]), gy),
+                        ws = self._wws[wkey] = (ops._ws(ops.query("dycon_colsum_workspace", gy.numel() // gy.shape[-1], gy.shape[-1]), gy),
                                                 ops.conv_wgrad_workspace(gy, x, CONV_K2S2))
                     ops.colsum(gy, gb, ws=ws[0])
                     ops.conv_wgrad(gy, x, gw, CONV_K2S2, 1, 8, Cout * 8, ws=ws[1])
                 else:                  # bias gradient = column sums of gy, fused into the wgrad pass
                     if ws is None:
-                        ws = self._wws[name] = ops.conv_wgrad_workspace(x, gy, mode)
+                        ws = self._wws[wkey] = ops.conv_wgrad_workspace(x, gy, mode)
                     ops.conv_wgrad(x, gy, gw, mode, 1 if T > 1 else 0, T, Cin * T, dbias=gb, ws=ws)
                 if self.on_param_grads is not None:
                     self.on_param_grads(name + ".weight")      # this layer's gradients are enqueued (DDP bucket trigger)
@@ -463,6 +464,16 @@ class Engine:
         V = z.numel() // (B * C)
         gamma = beta = None
         rm = rv = None
+        if kind == "bn" and chan_scale is not None:
+            # BatchNorm runs as ONE sample of B*V voxels, while nn.Dropout3d draws a mask per (sample, channel) (VNet.py:195-196,
+            # 225-226): the norm kernels index their dropout factor per norm-sample, so here the factor is applied by its own pass
+            y = self._norm(prefix, z, kind, relu=relu, skip=skip, training=training)
+            y2 = ops.scale_channels(y, chan_scale)
+            if self.recording:
+                def bwd_scale():
+                    self._give(y, ops.scale_channels(self._take(y2), chan_scale))
+                self.tape.append(bwd_scale)
+            return y2
         if kind == "gn":
             Nb, G = B, 16
             gamma, beta = self.p[prefix + ".weight"], self.p[prefix + ".bias"]
@@ -564,15 +575,15 @@ class Engine:
                 db = self.g[nname + ".bias"] if beta is not None else None
                 gw, gb = self.g[cname + ".weight"], self.g[cname + ".bias"]
                 if self.one_pass_first:       # everything in ONE pass over (x, z, gy), on the chain (it is the exposed tail of the backward)
-                    wws = self._wws.get(cname + "#fb")
+                    wws = self._wws.get((cname, "#fb", tuple(x.shape[:4])))
                     if wws is None:
-                        wws = self._wws[cname + "#fb"] = ops._ws(ops.query("dycon_first_block_bwd_workspace", *x.shape[:4]), x)
+                        wws = self._wws[(cname, "#fb", tuple(x.shape[:4]))] = ops._ws(ops.query("dycon_first_block_bwd_workspace", *x.shape[:4]), x)
                     ops.first_block_bwd(x, z, gy, stats, Nb, G, gw, gb, gamma, beta, True, dg, db, None, ws=wws)
                 else:
                     nws, ab = ops.norm_bwd_stats(z, gy, stats, Nb, V, C, G, gamma, beta, True, dg, db)
-                    wws = self._wws.get(cname + "#nb")
+                    wws = self._wws.get((cname, "#nb", tuple(x.shape[:4])))
                     if wws is None:
-                        wws = self._wws[cname + "#nb"] = ops._ws(ops.query("dycon_conv1_wgrad_normbwd_workspace", *x.shape[:4]), x)
+                        wws = self._wws[(cname, "#nb", tuple(x.shape[:4]))] = ops._ws(ops.query("dycon_conv1_wgrad_normbwd_workspace", *x.shape[:4]), x)
                     if self.wgrad_stream is not None:
                         ops.fork(ops.cur_stream(), self.wgrad_stream)
                         with ops.on_stream(self.wgrad_stream, light=True):
@@ -745,7 +756,10 @@ class Engine:
         u = up("block_six_up", block("block_six", u, 3), x3)
         u = up("block_seven_up", block("block_seven", u, 3), x2)
         u = up("block_eight_up", block("block_eight", u, 2), x1)
-        if self.fuse_head and nk != "none":          # block_nine's norm + ReLU + Dropout3d + out_conv in one pass (see _norm_head)
+        w9, wo = self.p["block_nine.conv.0.weight"], self.p["out_conv.weight"]
+        head_ok = w9.shape[0] == 16 and wo.shape[0] == 2           # the fused kernels are written for 16 channels -> 2 classes
+        bn_drop = nk == "bn" and self.dropout.mode != "off"        # per-sample Dropout3d masks under BatchNorm: unfused (see _norm)
+        if self.fuse_head and nk != "none" and head_ok and not bn_drop:   # block_nine's norm + ReLU + Dropout3d + out_conv in one pass
             z9 = self._conv("block_nine.conv.0", u, "k3", norm_groups=ngroups(u, "block_nine.conv.0"))
             cs9 = self._channel_scale(z9.shape[0], z9.shape[-1], "drop9", 0.5, 1, z9.device)
             logits = self._norm_head("block_nine.conv.1", z9, nk, "out_conv", training=training, chan_scale=cs9)

@@ -180,11 +180,15 @@ def _case_list(root_path, list_name, pattern):
         return [pattern.format(root=root_path, case=line.strip()) for line in f if line.strip()]
 
 
-def _mean_dice(model, cases, num_classes, patch_size, stride_xy, stride_z, label_key):
-    """validation during training: mean Dice of the sliding-window predictions (the var_all_case_* family, :52-74, :120-141, :188-209)"""
+def _mean_dice(model, cases, num_classes, patch_size, stride_xy, stride_z, label_key, transpose=None):
+    """validation during training: mean Dice of the sliding-window predictions (the var_all_case_* family, :52-74, :120-141, :188-209).
+    transpose: axis permutation applied to image AND label before the sliding window (BraTS19: (2, 1, 0), :64-65 -- the orientation
+    the training patches have after dataloaders.brats19.SagittalToAxial)."""
     total, n = 0.0, 0
     for case in cases:
         image, label = _read_case(case, label_key)
+        if transpose is not None:
+            image, label = np.transpose(np.asarray(image), transpose), np.transpose(np.asarray(label), transpose)
         pred, _ = test_single_case(model, image, stride_xy, stride_z, patch_size, num_classes=num_classes)
         if pred.sum() != 0:
             n_p, n_g, n_i = overlap_counts(pred, np.asarray(label))
@@ -195,11 +199,12 @@ def _mean_dice(model, cases, num_classes, patch_size, stride_xy, stride_z, label
 
 # per-dataset wrappers with the reference's names, defaults and on-disk layouts
 def var_all_case_BraTS19(model, root_path, num_classes, patch_size=(96, 96, 64), stride_xy=16, stride_z=4):
-    return _mean_dice(model, _case_list(root_path, "val.txt", "{root}/data/{case}.h5"), num_classes, patch_size, stride_xy, stride_z, "label")
+    return _mean_dice(model, _case_list(root_path, "val.txt", "{root}/data/{case}.h5"), num_classes, patch_size, stride_xy, stride_z, "label",
+                      transpose=(2, 1, 0))
 
 
 def var_all_case_Pancreas(model, root_path, num_classes, patch_size=(112, 112, 80), stride_xy=18, stride_z=4):
-    return _mean_dice(model, _case_list(root_path, "test.list", "{root}/Pancreas_data/{case}"), num_classes, patch_size, stride_xy, stride_z, "label")
+    return _mean_dice(model, _case_list(root_path, "test1.list", "{root}/Pancreas_data/{case}"), num_classes, patch_size, stride_xy, stride_z, "label")
 
 
 def var_all_case_ISLES22(root_path, model, num_classes, device=None, patch_size=(96, 96, 64), stride_xy=16, stride_z=4):

@@ -83,13 +83,22 @@ def test_pancreas_isles_transforms_and_samplers(tmp_path):
     r = I.RandomRot()({"image": img, "label": lab})
     np.testing.assert_array_equal(r["label"], ndimage.rotate(lab, angle, order=0, reshape=False))
     assert r["image"].shape == img.shape and set(np.unique(r["label"])) <= {0, 1}
-    # ThreeStreamBatchSampler: primary + secondary + primary from ONE primary permutation, two groups per batch
+    # ThreeStreamBatchSampler as the reference behaves: its two primary groupers iterate the SAME permutation array independently, so a
+    # batch is [primary group | secondary group | the same primary group] and an epoch has len(primary) // primary_batch_size batches
+    import itertools
+    smp = I.ThreeStreamBatchSampler(list(range(10)), list(range(10, 40)), batch_size=4, secondary_batch_size=2)
     np.random.seed(3)
-    batches = list(I.ThreeStreamBatchSampler(list(range(10)), list(range(10, 40)), batch_size=4, secondary_batch_size=2))
-    assert len(batches) == 2                      # 10 primaries: two batches of 2 + 2, the last pair of groups is incomplete
-    flat_primary = [i for b in batches for i in b[:2] + b[4:]]
-    assert all(i < 10 for i in flat_primary) and len(set(flat_primary)) == 8
-    assert all(len(b) == 6 and all(i >= 10 for i in b[2:4]) for b in batches)
+    batches = list(smp)
+    assert len(batches) == len(smp) == 5
+    assert all(len(b) == 6 and b[:2] == b[4:] and all(i < 10 for i in b[:2]) and all(i >= 10 for i in b[2:4]) for b in batches)
+    assert sorted(i for b in batches for i in b[:2]) == list(range(10))
+    # the same draws, restated with the reference's own construction (grouper = zip of n references to one iterator)
+    np.random.seed(3)
+    prim = np.random.permutation(list(range(10)))
+    sec = itertools.chain.from_iterable(np.random.permutation(list(range(10, 40))) for _ in itertools.count())
+    grouper = lambda it, n: zip(*[iter(it)] * n)  # noqa: E731
+    expect = [a + b + c for a, b, c in zip(grouper(prim, 2), grouper(sec, 2), grouper(prim, 2))]
+    assert [tuple(int(i) for i in b) for b in batches] == [tuple(int(i) for i in e) for e in expect]
     # dataset list handling (no h5py needed until a sample is read)
     (tmp_path / "train.list").write_text("case_a.h5\ncase_b.h5\ncase_c.h5\n")
     (tmp_path / "test.list").write_text("case_z.h5\n")

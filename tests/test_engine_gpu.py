@@ -165,6 +165,44 @@ def test_vnet_dropout3d_masks_vs_oracle():
         grad_within_budget(eng.g[k], dict(zip(names, grads))[k], grads64[k], k)
 
 
+def test_vnet_batchnorm_dropout3d_masks_vs_oracle():
+    """normalization='batchnorm' + Dropout3d with DIFFERENT keep-masks per sample (B = 4): BatchNorm runs as one sample of B*V voxels,
+    so the dropout factor cannot ride in the norm kernels (they index it per norm-sample) -- the engine applies it by its own pass and
+    leaves the fused head.  Forward and parameter gradients against the oracle (fp32 + fp64 twin)."""
+    from dycon_paper_replication_amd.engine import DropoutSpec, net_buffers
+    norm = "batchnorm"
+    p_all = ON.make_vnet_params(9, normalization=norm)
+    spec = param_spec("vnet", normalization=norm)
+    params = {k: p_all[k].to(DEV).contiguous() for k in spec}
+    grads = {k: torch.full_like(v, float("nan")) for k, v in params.items()}
+    bufs = {}
+    for k, shp in net_buffers("vnet", norm).items():
+        bufs[k] = (torch.zeros(shp, dtype=torch.long) if k.endswith("tracked") else
+                   (torch.ones(shp) if k.endswith("var") else torch.zeros(shp))).to(DEV)
+    eng = Engine("vnet", params, grads, bufs, dtype=torch.float32, normalization=norm)
+    torch.manual_seed(4)
+    x = torch.randn(4, 1, 48, 48, 48)
+    m5 = (torch.rand(4, 256) > 0.5).float()
+    m9 = (torch.rand(4, 16) > 0.5).float()
+    assert not torch.equal(m9[0], m9[1]) and not torch.equal(m5[0], m5[2])
+    r1, r2 = torch.randn(4, 2, 48, 48, 48), torch.randn(4, 256, 6, 6, 6)
+    names = list(ON.trainable(p_all))
+    leaves = {k: p_all[k].clone().requires_grad_(True) for k in names}
+    _, lo_ref, fe_ref = ON.vnet_forward(x, {**p_all, **leaves}, normalization=norm, drop5=m5, drop9=m9)
+    gr = dict(zip(names, torch.autograd.grad((lo_ref * r1).sum() + (fe_ref * r2).sum(), [leaves[k] for k in names])))
+    leaves64 = {k: p_all[k].double().clone().requires_grad_(True) for k in names}
+    _, lo64, fe64 = ON.vnet_forward(x.double(), {**_double(p_all), **leaves64}, normalization=norm, drop5=m5.double(), drop9=m9.double())
+    gr64 = dict(zip(names, torch.autograd.grad((lo64 * r1.double()).sum() + (fe64 * r2.double()).sum(), [leaves64[k] for k in names])))
+    dspec = DropoutSpec("mask", masks={"drop5": m5.to(DEV), "drop9": m9.to(DEV)})
+    logits, feats, _ = eng.forward(x.permute(0, 2, 3, 4, 1).contiguous().to(DEV), training=True, record=True, dropout=dspec)
+    within_budget(logits.cpu().permute(0, 4, 1, 2, 3).numpy(), lo_ref.detach().numpy(), lo64.detach().numpy(), "logits")
+    within_budget(feats.cpu().permute(0, 4, 1, 2, 3).numpy(), fe_ref.detach().numpy(), fe64.detach().numpy(), "feats")
+    eng.backward(r1.permute(0, 2, 3, 4, 1).contiguous().to(DEV), r2.permute(0, 2, 3, 4, 1).contiguous().to(DEV))
+    for k in ("block_nine.conv.0.weight", "block_nine.conv.1.weight", "block_five.conv.6.weight", "block_five.conv.7.weight", "out_conv.weight",
+              "block_one.conv.0.weight"):
+        grad_within_budget(eng.g[k], gr[k], gr64[k], k)
+
+
 def test_vnet_isles_geometry_vs_oracle():
     """BASELINE config 5 geometry: 112x112x80 patches (odd sizes 7x7x5 at the bottleneck, partial tiles everywhere),
     feature_scaler 4 -> 28x28x20 = 15 680 patch embeddings.  fp32 storage vs the oracle, forward only (B = 1)."""

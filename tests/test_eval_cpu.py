@@ -68,3 +68,44 @@ def test_largest_connected_component_known_answers():
     assert getLargestCC(empty) is empty          # no component: returned unchanged
     two = np.zeros((6, 6, 6), np.int64); two[0, 0, 0] = 1; two[3:5, 3:5, 3:5] = 1
     assert getLargestCC(two).sum() == 8
+
+
+def test_var_all_case_orientation_and_lists(tmp_path, monkeypatch):
+    """The in-training validation wrappers: BraTS19 transposes image AND label to (2, 1, 0) before the sliding window
+    (code/utils/test_3d_patch.py:64-65); Pancreas reads `test1.list` (:122), ISLES22 `val.list` with key `mask`, both untransposed."""
+    import importlib
+    t3 = importlib.import_module("dycon_paper_replication_amd.utils.test_3d_patch")
+    rng = np.random.default_rng(0)
+    image = rng.standard_normal((4, 6, 8)).astype(np.float32)
+    label = (rng.random((4, 6, 8)) > 0.5).astype(np.uint8)
+    seen = {}
+
+    def fake_read(case, key):
+        seen.setdefault("cases", []).append((case, key))
+        return image, label
+
+    def fake_single(model, img, sxy, sz, patch, num_classes=1, **kw):
+        seen["shape"] = img.shape
+        seen["image"] = np.array(img)
+        return (np.asarray(img) > 0).astype(np.int64), None       # a "prediction" that depends on the orientation it was given
+
+    monkeypatch.setattr(t3, "_read_case", fake_read)
+    monkeypatch.setattr(t3, "test_single_case", fake_single)
+    monkeypatch.setattr(t3, "overlap_counts", lambda p, g: (int(p.sum()), int(g.sum()), int((p.astype(bool) & g.astype(bool)).sum())))
+    (tmp_path / "val.txt").write_text("caseA\n\ncaseB\n")
+    (tmp_path / "test1.list").write_text("p1.h5\n")
+    (tmp_path / "val.list").write_text("i1\n")
+
+    d = t3.var_all_case_BraTS19(None, str(tmp_path), 2)
+    assert seen["shape"] == (8, 6, 4)
+    np.testing.assert_array_equal(seen["image"], np.transpose(image, (2, 1, 0)))
+    pt, lt = np.transpose(image, (2, 1, 0)) > 0, np.transpose(label, (2, 1, 0)).astype(bool)
+    assert d == pytest.approx(2.0 * (pt & lt).sum() / (pt.sum() + lt.sum()))
+    assert [c for c, _ in seen["cases"]] == [f"{tmp_path}/data/caseA.h5", f"{tmp_path}/data/caseB.h5"]
+
+    seen.clear()
+    t3.var_all_case_Pancreas(None, str(tmp_path), 2)
+    assert seen["shape"] == (4, 6, 8) and seen["cases"] == [(f"{tmp_path}/Pancreas_data/p1.h5", "label")]
+    seen.clear()
+    t3.var_all_case_ISLES22(str(tmp_path), None, 2)
+    assert seen["shape"] == (4, 6, 8) and seen["cases"] == [(f"{tmp_path}/i1.h5", "mask")]
