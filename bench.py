@@ -23,8 +23,12 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-MFMA_PEAK_TFLOPS = {"conv_gemm": 2500.0, "conv_k3_lds": 2500.0, "conv_k3_p16": 2500.0, "conv_k3_c1": 2500.0, "conv_k3_tile": 2500.0,
-                    "conv_gemm_splitk": 2500.0, "wgrad_k3_bf16": 2500.0, "conv_wgrad": 157.3}   # dense bf16 MFMA / f32-input MFMA (kernel's arithmetic type)
+# dense bf16 MFMA peak 2.5 PFLOP/s; kernels on the f32-input MFMA (v_mfma_f32_16x16x4_f32) or the vector unit: 157.3 TFLOP/s
+F32_MFMA_KERNELS = ("conv_wgrad_kernel", "conv_direct_kernel", "head_1x1", "grad_1x1_skinny")
+# algorithmic conv-I/O bytes (bf16) and FLOPs per training volume (student fwd + bwd + teacher fwd)
+ALGORITHMIC_PER_VOLUME = {("vnet", (96, 96, 96)): (1.186e9, 282.9e9), ("vnet", (112, 112, 80)): (1.345e9, 320.9e9),
+                          ("vnet", (112, 112, 96)): (1.614e9, 385.0e9), ("unet_3D", (96, 96, 96)): (1.657e9, 491.8e9),
+                          ("unet_3D", (112, 112, 80)): (1.879e9, 557.8e9)}
 
 
 def cpu_baseline(model, patch, seed):
@@ -74,6 +78,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)      # warm-up 10, time >= 50 steps (60 steps = 0.4 s on the GPU)
     ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--repeats", type=int, default=3, help="the timed region is run this many times; the median repeat is reported")
     ap.add_argument("--model", default="vnet", choices=["vnet", "unet_3D"])
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--batch", type=int, default=4)
@@ -133,25 +138,39 @@ def main():
     for _ in range(args.warmup):
         tr.step(vol, lab)
     barrier()
+    # SURVEY 8d protocol: the timed region is run REPEATS times back to back inside this invocation (each: exactly --steps steps
+    # between two barriers + synchronisations, max over ranks) and the MEDIAN repeat is reported; `ms_per_step_repeats` keeps all
     note("timed region")
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = tr.step(vol, lab)
-    barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        dt = float(t)
+    repeats = []
+    for _ in range(max(1, args.repeats)):
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            out = tr.step(vol, lab)
+        barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            dt = float(t)
+        repeats.append(dt)
+    dt = sorted(repeats)[len(repeats) // 2]
     ms_per_step = dt / args.steps * 1e3
     value = args.batch * world * args.steps / dt
-    note(f"{ms_per_step:.2f} ms/step, {value:.2f} volumes/s")
+    note(f"{ms_per_step:.3f} ms/step (repeats: {', '.join(f'{r / args.steps * 1e3:.3f}' for r in repeats)}), {value:.2f} volumes/s")
+    alg = ALGORITHMIC_PER_VOLUME.get((args.model, patch))
+    step_roofline = None
+    if alg is not None and args.dtype == "bf16":      # algorithmic conv I/O bytes and FLOPs per training volume, end to end
+        step_roofline = {"algorithmic_bytes_per_volume": alg[0], "algorithmic_flops_per_volume": alg[1],
+                         "step_hbm_frac": alg[0] * value / world / 1e9 / HBM_PEAK_GBS,
+                         "step_mfma_frac": alg[1] * value / world / 1e12 / 2500.0}
 
-    # ---- per-kernel roofline (HIP events on the launch stream, a few extra un-timed steps)
+    # ---- per-kernel roofline: every launch of the library bracketed by HIP timing events on its launch stream (csrc/ktimer.cpp),
+    # a few extra un-timed eager steps
     roofline = None
     nprof = 3
     if not args.no_kernel_timing:
-        # EVERY rank runs these extra steps (a step contains collectives when world > 1); only rank 0 brackets its launches
+        # EVERY rank runs these extra steps (a step contains collectives when world > 1); only rank 0 times its launches
         if rank == 0:
             ops.PROFILER = ops.KernelProfiler()
         tp0 = time.perf_counter()
@@ -160,58 +179,69 @@ def main():
         barrier()
         prof_ms_per_step = (time.perf_counter() - tp0) / nprof * 1e3
     if not args.no_kernel_timing and rank == 0:
+        ops.PROFILER.close()
         summ = ops.PROFILER.summary()
         ops.PROFILER = None
-        # The roofline object describes ONE kernel: pick the dominant region among the entry points that are a single launch
-        # (their event time is the kernel's duration, comparable with the rocprofv3 average); norm / wgrad / split-K entry points
-        # enqueue a finalize or reduce launch as well and are listed, per call, in per_kernel_*.
-        single = [k for k in summ if k in ("conv_k3_lds", "conv_k3_p16", "conv_k3_c1", "conv_gemm", "conv_direct")]
-        dom = max(single or summ, key=lambda k: summ[k]["ms"])
+        peak_of = lambda k: 157.3 if (args.dtype != "bf16" or any(t in k for t in F32_MFMA_KERNELS)) else 2500.0   # noqa: E731
+
+        def fracs(r, k):
+            sec = r["ms"] * 1e-3
+            return r["bytes"] / sec / 1e9 / HBM_PEAK_GBS, r["flops"] / sec / 1e12 / peak_of(k)
+        # The roofline object describes the kernel with the LARGEST share of the step among all kernels (every record is one kernel:
+        # finalize / reduce / finish launches are rows of their own, with no algorithmic bytes).  `secondary` keeps the largest
+        # matrix-core kernel beside it.
+        ranked = sorted(summ, key=lambda k: -summ[k]["ms"])
+        dom = ranked[0]
         r = summ[dom]
-        sec = r["ms"] * 1e-3
-        gbs = r["bytes"] / sec / 1e9
-        tfl = r["flops"] / sec / 1e12
-        peak_t = MFMA_PEAK_TFLOPS.get(dom, 157.3) if args.dtype == "bf16" else 157.3
-        f_hbm, f_mfma = gbs / HBM_PEAK_GBS, tfl / peak_t
-        bound = "hbm" if (r["bytes"] / (HBM_PEAK_GBS * 1e9)) >= (r["flops"] / (peak_t * 1e12)) else "mfma"
-        traffic = None     # HBM bytes per launch from the PMC passes committed under profiles/ (separate rocprofv3 --pmc runs)
-        try:
-            pmc_path = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
-            if not os.path.exists(pmc_path):
-                pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-            pmc = json.load(open(pmc_path))
-            traffic = pmc["per_region"][dom]["hbm_bytes_per_launch"]     # same unit as `achieved`: per launch of this kernel
-        except (OSError, KeyError, ValueError):
-            pass
-        # self-check of the table: a bracket that does not enclose its kernel shows up as a fraction above 1, and the brackets of
-        # one stream cannot add up to more than the (eager, profiled) step they were taken in
+        f_hbm, f_mfma = fracs(r, dom)
+        bound = "hbm" if (r["bytes"] / (HBM_PEAK_GBS * 1e9)) >= (r["flops"] / (peak_of(dom) * 1e12)) else "mfma"
+
+        def traffic_of(k):       # HBM bytes per launch from the PMC passes committed under profiles/ (separate rocprofv3 --pmc runs)
+            for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json"):
+                try:
+                    pmc = json.load(open(os.path.join(ROOT, "profiles", name)))["per_kernel"]
+                except (OSError, KeyError, ValueError):
+                    continue
+                base = k.replace(" ", "")
+                for pk, v in pmc.items():
+                    if pk.replace("void ", "").replace(" ", "") == base:
+                        return v["fetch_bytes_per_launch"] + v["write_bytes_per_launch"]
+            return None
+        # self-check of the table: a bracket that does not enclose its kernel shows up as a fraction above 1, and the kernels of one
+        # stream cannot add up to more than the (eager, profiled) step they were timed in
         main_stream = torch.cuda.current_stream().cuda_stream
         main_ms = sum(v["ms_by_stream"].get(main_stream, 0.0) for v in summ.values()) / nprof
-        fr = {k: (v["bytes"] / (v["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                  v["flops"] / (v["ms"] * 1e-3) / 1e12 / (MFMA_PEAK_TFLOPS.get(k, 157.3) if args.dtype == "bf16" else 157.3))
-              for k, v in summ.items() if v["ms"] > 0}
+        fr = {k: fracs(v, k) for k, v in summ.items() if v["ms"] > 0}
         over = sorted(k for k, (h, m) in fr.items() if h > 1.0 or m > 1.0)
         self_check = {"ok": not over and main_ms <= prof_ms_per_step * 1.02, "fractions_above_1": over,
-                      "main_stream_bracket_ms_per_step": round(main_ms, 4), "profiled_step_ms": round(prof_ms_per_step, 4)}
+                      "main_stream_kernel_ms_per_step": round(main_ms, 4), "profiled_step_ms": round(prof_ms_per_step, 4)}
         if not self_check["ok"]:
             note(f"SELF-CHECK FAILED: {self_check}")
             if args.strict:
                 raise SystemExit(f"bench self-check failed: {self_check}")
-        roofline = {"kernel": dom, "bound": bound, "self_check": self_check,
-                    "achieved": gbs if bound == "hbm" else tfl, "peak": HBM_PEAK_GBS if bound == "hbm" else peak_t,
-                    "unit": "GB/s" if bound == "hbm" else "TFLOP/s", "frac": f_hbm if bound == "hbm" else f_mfma,
-                    "traffic": traffic, "algorithmic_bytes_per_launch": r["bytes"] / r["launches"],
-                    "algorithmic_flops_per_launch": r["flops"] / r["launches"],
-                    "avg_launch_ms": r["ms"] / r["launches"], "launches_per_step": r["launches"] // nprof,
-                    "hbm_frac": f_hbm, "mfma_frac": f_mfma,
-                    "per_kernel_ms_per_step": {k: round(v["ms"] / nprof, 4) for k, v in sorted(summ.items(), key=lambda kv: -kv[1]["ms"])},
-                    "per_kernel_algorithmic_bytes_per_step": {k: v["bytes"] / nprof for k, v in summ.items()},
-                    "per_kernel_calls_per_step": {k: v["launches"] // nprof for k, v in summ.items()},
-                    # every kernel family against BOTH ceilings (algorithmic bytes / flops over the summed launch durations)
-                    "per_kernel_frac": {k: {"hbm": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                                            "mfma": round(v["flops"] / (v["ms"] * 1e-3) / 1e12 /
-                                                          (MFMA_PEAK_TFLOPS.get(k, 157.3) if args.dtype == "bf16" else 157.3), 4)}
-                                        for k, v in sorted(summ.items(), key=lambda kv: -kv[1]["ms"]) if v["ms"] > 0}}
+
+        def entry(k):
+            v = summ[k]
+            h, m = fracs(v, k)
+            b = "hbm" if (v["bytes"] / (HBM_PEAK_GBS * 1e9)) >= (v["flops"] / (peak_of(k) * 1e12)) else "mfma"
+            sec = v["ms"] * 1e-3
+            return {"kernel": k, "bound": b, "achieved": v["bytes"] / sec / 1e9 if b == "hbm" else v["flops"] / sec / 1e12,
+                    "peak": HBM_PEAK_GBS if b == "hbm" else peak_of(k), "unit": "GB/s" if b == "hbm" else "TFLOP/s",
+                    "frac": h if b == "hbm" else m, "traffic": traffic_of(k),
+                    "algorithmic_bytes_per_launch": v["bytes"] / v["launches"], "algorithmic_flops_per_launch": v["flops"] / v["launches"],
+                    "avg_launch_ms": v["ms"] / v["launches"], "launches_per_step": v["launches"] // nprof,
+                    "ms_per_step": v["ms"] / nprof, "hbm_frac": h, "mfma_frac": m}
+        mfma_kernels = [k for k in ranked if summ[k]["flops"] / (peak_of(k) * 1e12) > summ[k]["bytes"] / (HBM_PEAK_GBS * 1e9)]
+        roofline = entry(dom)
+        roofline.update({
+            "self_check": self_check, "selection": "largest summed HIP-event duration over ALL kernels of the step",
+            "secondary": entry(mfma_kernels[0]) if mfma_kernels and mfma_kernels[0] != dom else None,
+            "step": step_roofline,
+            "per_kernel": {k: {"ms_per_step": round(summ[k]["ms"] / nprof, 4), "launches_per_step": summ[k]["launches"] // nprof,
+                               "avg_launch_us": round(summ[k]["ms"] / summ[k]["launches"] * 1e3, 2),
+                               "algorithmic_bytes_per_step": summ[k]["bytes"] / nprof, "algorithmic_flops_per_step": summ[k]["flops"] / nprof,
+                               "hbm_frac": round(fr[k][0], 4) if k in fr else None, "mfma_frac": round(fr[k][1], 4) if k in fr else None,
+                               "entry_points": summ[k]["regions"]} for k in ranked}})
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -221,7 +251,8 @@ def main():
 
     if rank == 0:
         line = {"metric": "train volumes/sec (96^3 patch)", "value": value, "unit": "volumes/s", "n_gpus": world, "steps": args.steps,
-                "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                "warmup": args.warmup, "ms_per_step": ms_per_step, "repeats": len(repeats),
+                "ms_per_step_repeats": [round(r / args.steps * 1e3, 4) for r in repeats], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                 "dtype": args.dtype, "data": "synthetic",
                 "config": {"workload": f"BraTS2019 labelnum=25 geometry, {args.model} (GroupNorm) {args.dtype}, per-GPU batch "
                                        f"{args.batch} ({args.labeled} lab + {args.batch - args.labeled} unlab), "

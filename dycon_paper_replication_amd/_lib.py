@@ -99,6 +99,10 @@ SIGNATURES = {
     "dycon_sw_finalize": (I, [P, P, L, F, P, P, P]),
     "dycon_binary_overlap": (I, [P, P, I, L, P, P]),
     "dycon_batch_overlap": (I, [P, P, I, I, L, P, P]),
+    "dycon_kernel_timing": (I, [I]),
+    "dycon_kernel_timing_count": (L, []),
+    "dycon_kernel_timing_fetch": (I, [L, L, P, P, P]),
+    "dycon_kernel_timing_name": (C.c_char_p, [I]),
 }
 
 
@@ -160,13 +164,14 @@ RECORDER = None
 # ---------------------------------------------------------------- HIP runtime: events of the step's fork / join structure
 # torch.cuda.Event() is created with hipEventDisableTiming only, so every record carries a SYSTEM-scope release (cache write-back
 # and invalidate, hip_runtime_api.h: hipEventDisableSystemFence).  The step's ~50 cross-stream dependencies are device-local
-# (producer and consumer kernels on the same GPU): their events are created here with the fence narrowed, and recorded / waited
-# through ctypes (also cheaper on the host than the torch objects).  DYCON_EVENT_FLAGS = default | nofence | device (diagnostic).
+# (producer and consumer kernels on the same GPU; the one host-read value of a step, the NaN flag, keeps torch's event): their
+# events are created here without that fence and recorded / waited through ctypes (also cheaper on the host than the torch objects).
+# Measured (profiles/r03_ablation_timing.txt): step 5.05 ms with torch's flags, 4.95 ms with hipEventDisableSystemFence, 5.05 ms with
+# hipEventReleaseToDevice (the release flags are mutually exclusive).  DYCON_EVENT_FLAGS = default | nofence | device (diagnostic).
 HIP_EVENT_DISABLE_TIMING, HIP_EVENT_NO_SYSTEM_FENCE, HIP_EVENT_RELEASE_TO_DEVICE = 0x2, 0x20000000, 0x40000000
 _EVENT_FLAGS = {"default": HIP_EVENT_DISABLE_TIMING, "nofence": HIP_EVENT_DISABLE_TIMING | HIP_EVENT_NO_SYSTEM_FENCE,
-                "device": HIP_EVENT_DISABLE_TIMING | HIP_EVENT_RELEASE_TO_DEVICE,
-                "device_nofence": HIP_EVENT_DISABLE_TIMING | HIP_EVENT_RELEASE_TO_DEVICE | HIP_EVENT_NO_SYSTEM_FENCE}
-EVENT_MODE = os.environ.get("DYCON_EVENT_FLAGS", "device")
+                "device": HIP_EVENT_DISABLE_TIMING | HIP_EVENT_RELEASE_TO_DEVICE}
+EVENT_MODE = os.environ.get("DYCON_EVENT_FLAGS", "nofence")
 _hip = None
 
 

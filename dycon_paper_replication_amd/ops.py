@@ -110,24 +110,68 @@ def fork(src, dst):
 
 # ------------------------------------------------------------------ optional per-kernel timing (bench.py)
 class KernelProfiler:
-    """HIP-event timing of individual entry points on the launch stream (ops.cur_stream()), with the
-    ALGORITHMIC bytes / flops of every launch (inputs + outputs read/written once, true K/N without padding)."""
+    """Per-KERNEL timing of the step (bench.py's roofline object): the library brackets every launch it makes with two HIP timing
+    events on the launch stream (csrc/ktimer.cpp, dycon_kernel_timing); the wrappers of this module note, per entry-point call, which
+    records it produced and the ALGORITHMIC bytes / flops of the call (inputs + outputs read / written once, true K / N without
+    padding).  Those are attributed to the call's kernels by name (`parts`: the statistics and the apply pass of a normalisation
+    each move their own bytes) or, by default, to its longest kernel; the finalize / reduce / finish launches of a call are
+    records of their own with no algorithmic bytes -- every figure is a kernel's, as in `rocprofv3 --kernel-trace --stats`."""
 
     def __init__(self):
-        self.rec = {}
+        call("dycon_kernel_timing", 1)
+        self.regions = []          # (region name, first record, one past the last record, bytes, flops, parts)
 
-    def add(self, name, e0, e1, nbytes, flops, stream):
-        self.rec.setdefault(name, []).append((e0, e1, nbytes, flops, stream))
+    def count(self):
+        return _lib.load().dycon_kernel_timing_count()
+
+    def add(self, name, i0, i1, nbytes, flops, parts):
+        if i1 > i0:
+            self.regions.append((name, i0, i1, nbytes, flops, parts))
+
+    def close(self):
+        call("dycon_kernel_timing", 0)
 
     def summary(self):
-        """per region: launches, summed bracket time, algorithmic bytes / flops, and the bracket time per launch stream"""
+        """kernel name -> {launches, ms, bytes, flops, ms_by_stream, regions}; waits for the recorded launches"""
+        import ctypes as C
+        lib = _lib.load()
+        n = lib.dycon_kernel_timing_count()
+        ms, st, nm = (C.c_float * n)(), (C.c_ulonglong * n)(), (C.c_int * n)()
+        rc = lib.dycon_kernel_timing_fetch(0, n, ms, st, nm)
+        if rc:
+            raise _lib.DyconLibraryError(f"dycon_kernel_timing_fetch failed ({rc}): {lib.dycon_last_error().decode()}")
+        names = {}
+        kname = lambda i: names.setdefault(nm[i], lib.dycon_kernel_timing_name(nm[i]).decode())   # noqa: E731
         out = {}
-        for name, rows in self.rec.items():
-            per_stream = {}
-            for a, b, _, _, st in rows:
-                per_stream[st] = per_stream.get(st, 0.0) + a.elapsed_time(b)
-            out[name] = {"launches": len(rows), "ms": sum(per_stream.values()), "bytes": sum(r[2] for r in rows),
-                         "flops": sum(r[3] for r in rows), "ms_by_stream": per_stream}
+
+        def row(i):
+            r = out.setdefault(kname(i), {"launches": 0, "ms": 0.0, "bytes": 0, "flops": 0, "ms_by_stream": {}, "regions": set()})
+            return r
+        owned = [None] * n
+        for name, i0, i1, nbytes, flops, parts in self.regions:
+            for i in range(i0, i1):
+                owned[i] = name
+            matched = False
+            if parts:
+                for sub, b, f in parts:
+                    hit = [i for i in range(i0, i1) if sub in kname(i)]
+                    if hit:
+                        matched = True
+                        r = row(max(hit, key=lambda i: ms[i]))
+                        r["bytes"] += b
+                        r["flops"] += f
+            if not matched:
+                r = row(max(range(i0, i1), key=lambda i: ms[i]))
+                r["bytes"] += nbytes
+                r["flops"] += flops
+        for i in range(n):
+            r = row(i)
+            r["launches"] += 1
+            r["ms"] += ms[i]
+            r["ms_by_stream"][st[i]] = r["ms_by_stream"].get(st[i], 0.0) + ms[i]
+            r["regions"].add(owned[i] or "-")
+        for r in out.values():
+            r["regions"] = sorted(r["regions"])
         return out
 
 
@@ -135,20 +179,16 @@ PROFILER: Optional[KernelProfiler] = None
 
 
 class _Timed:
-    __slots__ = ("name", "nbytes", "flops", "e0")
+    __slots__ = ("name", "nbytes", "flops", "parts", "i0")
 
-    def __init__(self, name, nbytes, flops):
-        self.name, self.nbytes, self.flops = name, nbytes, flops
+    def __init__(self, name, nbytes, flops, parts):
+        self.name, self.nbytes, self.flops, self.parts = name, nbytes, flops, parts
 
     def __enter__(self):
-        self.e0 = torch.cuda.Event(enable_timing=True)
-        self.e0.record(cur_stream())      # the stream THIS package launches on (side-stream sections redirect only that)
+        self.i0 = PROFILER.count()
 
     def __exit__(self, *a):
-        e1 = torch.cuda.Event(enable_timing=True)
-        st = cur_stream()
-        e1.record(st)
-        PROFILER.add(self.name, self.e0, e1, self.nbytes, self.flops, st.cuda_stream)
+        PROFILER.add(self.name, self.i0, PROFILER.count(), self.nbytes, self.flops, self.parts)
 
 
 class _Untimed:
@@ -164,9 +204,10 @@ class _Untimed:
 _UNTIMED = _Untimed()
 
 
-def _Region(name, nbytes, flops):
-    """HIP-event bracket around one entry point while bench.py profiles; a shared no-op object otherwise."""
-    return _UNTIMED if PROFILER is None else _Timed(name, nbytes, flops)
+def _Region(name, nbytes, flops, parts=None):
+    """Accounting bracket around one entry point while bench.py profiles (see KernelProfiler); a shared no-op object otherwise.
+    parts: [(kernel-name substring, bytes, flops), ...] where the call's bytes belong to more than one of its kernels."""
+    return _UNTIMED if PROFILER is None else _Timed(name, nbytes, flops, parts)
 
 
 def _es(t):
@@ -349,7 +390,7 @@ def colsum(x2d_like, out, ws=None):
 def norm_stats(x, Nb, V, C, G, eps=1e-5, running_mean=None, running_var=None, momentum=0.1):
     stats = torch.empty(Nb * G * 2, dtype=torch.float32, device=x.device)
     ws = _ws(query("dycon_norm_workspace", Nb, V, C), x)
-    with _Region("norm_fwd", x.numel() * _es(x), 3 * x.numel()):
+    with _Region("norm_stats", x.numel() * _es(x), 3 * x.numel()):
         call("dycon_norm_stats", _p(x), dt(x), Nb, V, C, G, eps, _p(stats), _p(running_mean), _p(running_var), momentum,
              _p(ws), ws.numel() * 4, _s())
     return stats
@@ -367,7 +408,9 @@ def norm_fwd(x, Nb, V, C, G, gamma=None, beta=None, relu=True, skip=None, chan_s
                  _p(chan_scale), _p(running_mean), _p(running_var), momentum, _p(acc), _s())
         return y, stats
     ws = _ws(query("dycon_norm_workspace", Nb, V, C), x)
-    with _Region("norm_fwd", x.numel() * _es(x) * (4 if skip is not None else 3), 6 * x.numel()):
+    nb = x.numel() * _es(x)
+    with _Region("norm_fwd", nb * (4 if skip is not None else 3), 6 * x.numel(),
+                 parts=[("partial", nb, 3 * x.numel()), ("apply", nb * (3 if skip is not None else 2), 3 * x.numel())]):
         call("dycon_norm_fwd", _p(x), _p(y), dt(x), Nb, V, C, G, eps, _p(stats), _p(gamma), _p(beta), int(relu), _p(skip),
              _p(chan_scale), _p(running_mean), _p(running_var), momentum, _p(ws), ws.numel() * 4, _s())
     return y, stats
@@ -419,8 +462,9 @@ def norm_bwd(src, from_y, gy, stats, Nb, V, C, G, gamma=None, beta=None, relu=Tr
                  _p(chan_scale), _p(dgamma), _p(dbeta), _p(acc), _p(ws), ws.numel() * 4 if fused else 0, _s())
         return out
     ws = _ws(query("dycon_norm_workspace", Nb, V, C), gy)
+    nb = gy.numel() * _es(gy)
     deferred = bool(defer_dparams) and not from_y and (dgamma is not None or dbeta is not None) and norm_fwd_is_fused(gy, V, C, G)
-    with _Region("norm_bwd", gy.numel() * _es(gy) * 5, 12 * gy.numel()):
+    with _Region("norm_bwd", nb * 5, 12 * gy.numel(), parts=[("partial", 2 * nb, 6 * gy.numel()), ("apply", 3 * nb, 6 * gy.numel())]):
         call("dycon_norm_bwd_ex", _p(src), int(from_y), _p(gy), _p(out), dt(gy), Nb, V, C, G, _p(stats), _p(gamma), _p(beta),
              int(relu), _p(chan_scale), _p(dgamma), _p(dbeta), int(deferred), _p(ws), ws.numel() * 4, _s())
     if defer_dparams:
@@ -441,7 +485,9 @@ def norm_head_bwd(x, g_logits, stats, Nb, V, G, head_w, gamma=None, beta=None, r
     """returns (gx, pending): pending -> norm_head_dparams(pending, d_head_w, d_head_b) on any stream"""
     gx = torch.empty_like(x)
     ws = _ws(query("dycon_norm_head_workspace", Nb, V), x)
-    with _Region("norm_bwd", x.numel() * _es(x) * 3 + g_logits.numel() * 8, 14 * x.numel()):
+    nb = x.numel() * _es(x)
+    with _Region("norm_bwd", nb * 3 + g_logits.numel() * 8, 14 * x.numel(),
+                 parts=[("partial", nb + g_logits.numel() * 4, 7 * x.numel()), ("apply", 2 * nb + g_logits.numel() * 4, 7 * x.numel())]):
         call("dycon_norm_head_bwd", _p(x), _p(g_logits), _p(gx), dt(x), Nb, V, G, _p(stats), _p(gamma), _p(beta), int(relu),
              _p(chan_scale), _p(head_w), _p(dgamma), _p(dbeta), _p(ws), ws.numel() * 4, _s())
     return gx, (ws, Nb, V)

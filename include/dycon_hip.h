@@ -408,6 +408,17 @@ int dycon_binary_overlap(const uint8_t* pred, const void* gt, int gt_bytes, long
 int dycon_batch_overlap(const float* logits, const void* gt, int gt_bytes, int B, long long V,
                         unsigned long long* out3b, dycon_stream_t stream);
 
+/* ---------------------------------------------------------------- per-kernel timing (bench.py `roofline`; diagnostics)
+ * dycon_kernel_timing(1): from now on every kernel this library launches is bracketed by two HIP timing events on its launch
+ * stream (earlier records are dropped); (0): stop.  Each LAUNCH is one record -- the finalize / reduce launch an entry point
+ * enqueues after its main kernel is a record of its own.  _count: launches recorded so far (callers bracket an entry point by
+ * reading it before and after the call).  _fetch: durations (ms), launch streams and kernel-name ids of records [first, first+n);
+ * waits for those launches.  _name: the demangled kernel name of an id.  Not thread-safe; timing runs are single-threaded. */
+int dycon_kernel_timing(int on);
+long long dycon_kernel_timing_count(void);
+int dycon_kernel_timing_fetch(long long first, long long n, float* ms, unsigned long long* stream, int* name_id);
+const char* dycon_kernel_timing_name(int id);
+
 #ifdef __cplusplus
 }
 #endif

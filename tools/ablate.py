@@ -55,5 +55,5 @@ if __name__ == "__main__":
     run("no norm backward (gz := gy)", ablate=("norm_bwd",))
     run("no data-gradient convs (gx := 0-size alias)", ablate=("dgrad",))
     run("single stream (all overlaps off)", overlap_teacher=False, overlap_wgrad=False, overlap_features=False)
-    for mode in ("default", "nofence", "device", "device_nofence"):
+    for mode in ("default", "nofence", "device"):
         run(f"fork / join events created with DYCON_EVENT_FLAGS={mode}", env={"DYCON_EVENT_FLAGS": mode})
