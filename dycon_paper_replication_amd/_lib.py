@@ -78,6 +78,7 @@ SIGNATURES = {
     "dycon_seg_losses_bwd": (I, [P, P, P, I, I, I, L, F, P, P, I, P, I, P]),
     "dycon_seg_losses_finalize": (I, [P, I, I, L, F, P, P]),
     "dycon_step_loss": (I, [P, P, F, F, F, I, I, P, P, P]),
+    "dycon_step_losses": (I, [P, P, I, I, L, F, C.c_double, F, I, F, F, F, I, I, P, P, P]),
     "dycon_softmax_mse_fwd": (I, [P, P, P, L, I, L, I, P]),
     "dycon_softmax_mse_bwd": (I, [P, P, P, P, L, I, L, I, P]),
     "dycon_softmax_kl_fwd": (I, [P, P, L, I, L, I, P, P, P]),

@@ -164,6 +164,29 @@ __global__ void step_loss_kernel(const float* __restrict__ vals, const float* __
     if (nonfinite) nonfinite[0] = isfinite(total) ? 0 : 1;
 }
 
+// seg_losses_finalize + fecl_finalize + step_loss in one launch (same arithmetic, same order)
+__global__ void step_losses_kernel(const double* __restrict__ sums, const double* __restrict__ fo, int B, int LB, long long V,
+                                   float beta, double fecl_rows, float lambda_cross, int has_teacher, float l_w, float cons_w,
+                                   float u_w, int dice_kind, int cons_kind, float* __restrict__ out, int* __restrict__ nonfinite) {
+    const double s = 1e-5;
+    const double nl = (double)LB * (double)V, nc = (double)(B - LB) * (double)V * 2.0, na = (double)B * (double)V;
+    const double d1 = 1.0 - (2.0 * sums[1] + s) / (sums[2] + sums[3] + s);
+    const double d0 = 1.0 - (2.0 * sums[4] + s) / (sums[5] + sums[6] + s);
+    const float ce = LB > 0 ? (float)(sums[0] / nl) : 0.f;
+    const float dice = dice_kind ? (float)(0.5 * (d0 + d1)) : (float)d1;
+    const float cons = B > LB ? (float)(sums[cons_kind ? 8 : 7] / nc) : 0.f;
+    const float un = (float)(sums[9] / na + (double)beta * sums[10] / na);
+    float fe = 0.f;
+    if (fo) {
+        double l = fo[0] / fecl_rows;
+        if (has_teacher) l += (double)lambda_cross * fo[1] / (fo[2] + 1e-18);
+        fe = (float)l;
+    }
+    const float total = l_w * (ce + dice) + cons_w * cons + u_w * (fe + un);
+    out[0] = total; out[1] = ce; out[2] = dice; out[3] = cons; out[4] = fe; out[5] = un;
+    if (nonfinite) nonfinite[0] = isfinite(total) ? 0 : 1;
+}
+
 // =================================================================================================
 // row L2 normalisation: one wave per row
 // =================================================================================================
@@ -783,6 +806,16 @@ extern "C" int dycon_step_loss(const float* vals, const float* fecl, float l_wei
                                int dice_kind, int cons_kind, float* out, int* nonfinite, dycon_stream_t stream) {
     DYCON_REQUIRE(vals && out, "step_loss: bad arguments");
     step_loss_kernel<<<1, 1, 0, stream>>>(vals, fecl, l_weight, cons_weight, u_weight, dice_kind, cons_kind, out, nonfinite);
+    DYCON_LAUNCH_CHECK();
+    return DYCON_OK;
+}
+
+extern "C" int dycon_step_losses(const double* sums, const double* fecl_out, int B, int LB, long long V, float beta, double fecl_rows,
+                                 float lambda_cross, int has_teacher, float l_weight, float cons_weight, float u_weight,
+                                 int dice_kind, int cons_kind, float* out, int* nonfinite, dycon_stream_t stream) {
+    DYCON_REQUIRE(sums && out && B > 0 && LB >= 0 && LB <= B && V > 0 && (!fecl_out || fecl_rows > 0), "step_losses: bad arguments");
+    step_losses_kernel<<<1, 1, 0, stream>>>(sums, fecl_out, B, LB, V, beta, fecl_rows, lambda_cross, has_teacher, l_weight, cons_weight,
+                                            u_weight, dice_kind, cons_kind, out, nonfinite);
     DYCON_LAUNCH_CHECK();
     return DYCON_OK;
 }

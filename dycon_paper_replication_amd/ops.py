@@ -651,11 +651,12 @@ def _label_bytes(labels):
     raise TypeError("labels must be int64 or uint8")
 
 
-def seg_losses_fwd(s_logits, t_logits, labels, LB, beta, fast=False):
-    """s/t_logits: (B, D, H, W, 2) fp32; returns sums (16 doubles on device).  fast: hardware exp/log sequences (bf16 step)."""
+def seg_losses_fwd(s_logits, t_logits, labels, LB, beta, fast=False, out=None):
+    """s/t_logits: (B, D, H, W, 2) fp32; returns sums (16 doubles on device; `out`: the caller's buffer).  fast: hardware exp/log
+    sequences (bf16 step)."""
     B = s_logits.shape[0]
     V = s_logits.numel() // (2 * B)
-    sums = torch.empty(16, dtype=torch.float64, device=s_logits.device)
+    sums = out if out is not None else torch.empty(16, dtype=torch.float64, device=s_logits.device)
     call("dycon_seg_losses_fwd", _p(s_logits), _p(t_logits), _p(labels), _label_bytes(labels), B, LB, V, float(beta), _p(sums), int(fast), _s())
     return sums
 
@@ -673,6 +674,15 @@ def seg_losses_finalize(sums, B, LB, V, beta):
     vals = torch.empty(8, dtype=torch.float32, device=sums.device)
     call("dycon_seg_losses_finalize", _p(sums), B, LB, V, float(beta), _p(vals), _s())
     return vals
+
+
+def step_losses(sums, fecl_out, B, LB, V, beta, fecl_rows, lambda_cross, has_teacher, l_w, cons_w, u_w, dice_kind, cons_kind,
+                nonfinite=None):
+    """seg_losses_finalize + fecl_finalize + step_loss as one launch, from the raw accumulators (out[6]: total, ce, dice, cons, fecl, uncl)"""
+    out = torch.empty(8, dtype=torch.float32, device=sums.device)
+    call("dycon_step_losses", _p(sums), _p(fecl_out), B, LB, V, float(beta), float(fecl_rows), float(lambda_cross), int(bool(has_teacher)),
+         float(l_w), float(cons_w), float(u_w), dice_kind, cons_kind, _p(out), _p(nonfinite), _s())
+    return out
 
 
 def step_loss(vals, fecl, l_w, cons_w, u_w, dice_kind, cons_kind, nonfinite=None):
@@ -711,11 +721,11 @@ class FeclState:
     __slots__ = ("out", "ws", "loss")
 
 
-def fecl_fwd(feat, teacher, mask, gambling, temperature, gamma, use_focal, cross_thresh, lambda_cross):
-    """feat/teacher (B, N, Dm) normalised rows; mask (B, N) float.  Returns (loss[1] fp32, state)."""
+def fecl_fwd(feat, teacher, mask, gambling, temperature, gamma, use_focal, cross_thresh, lambda_cross, out=None):
+    """feat/teacher (B, N, Dm) normalised rows; mask (B, N) float.  Returns (loss[1] fp32, state); `out`: the caller's 4 doubles."""
     B, N, Dm = feat.shape
     st = FeclState()
-    st.out = torch.empty(4, dtype=torch.float64, device=feat.device)
+    st.out = out if out is not None else torch.empty(4, dtype=torch.float64, device=feat.device)
     st.loss = torch.empty(1, dtype=torch.float32, device=feat.device)
     st.ws = _ws(query("dycon_fecl_workspace", B, N, Dm), feat)
     call("dycon_fecl_fwd", _p(feat), _p(teacher), _p(mask), _p(gambling), dt(feat), B, N, Dm, temperature, gamma,

@@ -161,6 +161,7 @@ class DyconTrainer:
         self.sumsq = torch.zeros(1, dtype=torch.float64, device=self.device)
         self.flag = torch.zeros(1, dtype=torch.int32, device=self.device)
         self.coef = torch.zeros(8, dtype=torch.float32, device=self.device)
+        self.acc20 = torch.zeros(20, dtype=torch.float64, device=self.device)      # [0:16] voxel-loss sums, [16:20] FeCL accumulators
         self.skipped_steps = 0
         # the NaN/Inf flag is final once step_loss has run: it is copied to pinned host memory right there and read at the end
         # of the step, when the copy has long completed -- the host never waits for the backward, the GPU never runs dry
@@ -296,14 +297,14 @@ class DyconTrainer:
         for name, (idx, stride) in self._PHILOX.items():
             for e in by.get(name, ()):
                 e[1][idx] = base[id(e)][idx] + (it - rp["it"]) * stride
-        for name, idx in (("dycon_seg_losses_fwd", 7), ("dycon_seg_losses_bwd", 7), ("dycon_seg_losses_finalize", 4)):
+        for name, idx in (("dycon_seg_losses_fwd", 7), ("dycon_seg_losses_bwd", 7), ("dycon_step_losses", 5)):
             for e in by.get(name, ()):
                 e[1][idx] = float(beta)
         for name in ("dycon_fecl_fwd", "dycon_fecl_bwd"):
             for e in by.get(name, ()):
                 e[1][11] = thr
-        for e in by.get("dycon_step_loss", ()):
-            e[1][3] = float(cw)
+        for e in by.get("dycon_step_losses", ()):
+            e[1][10] = float(cw)
         for e in by.get("dycon_set_scalars", ()):           # coef = (l_w, l_w*(1-dk)*gw, l_w*dk*gw, cw, u_w, u_w): only cw moves
             e[1][5] = float(cw)
         for e in by.get("dycon_sgd_ema", ()):
@@ -400,7 +401,9 @@ class DyconTrainer:
         # ---- losses (:308-357)
         world = self.world
         glob = self.ddp and c.global_batch_losses
-        sums = ops.seg_losses_fwd(s_logits, t_logits, label, LB, beta, fast=self._fast_math)
+        # the step's 16 + 4 loss accumulators live in ONE buffer: a data-parallel run exchanges them with one all-reduce
+        sums, fo = self.acc20[:16], self.acc20[16:]
+        ops.seg_losses_fwd(s_logits, t_logits, label, LB, beta, fast=self._fast_math, out=sums)
         fctx = (lambda: ops.on_stream(self.feat)) if self.feat is not None else contextlib.nullcontext
         with fctx():
             if self.feat is not None:                     # teacher features (the student's head was enqueued on self.feat)
@@ -413,24 +416,24 @@ class DyconTrainer:
             mask = ops.mask_pool(label, k)                                                   # :326-330
             teacher_emb = t_emb if c.use_teacher_loss else None
             fargs = (s_emb, teacher_emb, mask, None, c.temp, c.gamma, bool(c.use_focal), thr)
-            f_loss, fst = ops.fecl_fwd(*fargs, 1.0)
+            f_loss, fst = ops.fecl_fwd(*fargs, 1.0, out=fo)
             self._mark("fecl_fwd_end")
         if self.feat is not None:
             ops.fork(feat, main)       # the scalar loss (and the DDP exchange below) needs the FeCL sums
-            for t in (t_feat, f_loss, fst.out, mask):
+            for t in (t_feat, mask):
                 t.record_stream(main)
         gw = 1
         if glob:
             # Dice is a ratio of batch-GLOBAL sums (losses.py:11-14) and the FeCL cross branch a global sum over a
-            # global count (dycon_losses.py:229): exchange the 16 + 4 accumulators, then finalise on every rank
-            fo = fst.out
-            ops.rec(lambda: (torch.distributed.all_reduce(sums, group=self.pg), torch.distributed.all_reduce(fo, group=self.pg)))
-            f_loss = ops.fecl_finalize(fst, B * world * s_emb.shape[1], 1.0, teacher_emb is not None)
+            # global count (dycon_losses.py:229): exchange the 16 + 4 accumulators (one collective), then finalise on every rank
+            acc20 = self.acc20
+            ops.rec(lambda: torch.distributed.all_reduce(acc20, group=self.pg))
             gw = world
-        vals = ops.seg_losses_finalize(sums, B * gw, LB * gw, V, beta)
         dice_kind = 0 if c.dice_variant == "fg" else 1
         cons_kind = 0 if c.consistency_type == "mse" else 1
-        out = ops.step_loss(vals, f_loss, c.l_weight, cw, c.u_weight, dice_kind, cons_kind, self.flag)   # :355-362
+        # the scalar end of the loss forward (:355-362) in one launch: voxel-loss ratios, FeCL finalize, weighted total, NaN/Inf flag
+        out = ops.step_losses(sums, fo, B * gw, LB * gw, V, beta, B * gw * s_emb.shape[1], 1.0, teacher_emb is not None,
+                              c.l_weight, cw, c.u_weight, dice_kind, cons_kind, self.flag)
         if c.strict_nan_check:
             ops.rec(lambda: (self.flag_host.copy_(self.flag, non_blocking=True), self.flag_evt.record(main)))
 

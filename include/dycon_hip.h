@@ -307,6 +307,13 @@ int dycon_seg_losses_finalize(const double* sums, int B, int LB, long long V, fl
 int dycon_step_loss(const float* vals, const float* fecl, float l_weight, float cons_weight,
                     float u_weight, int dice_kind, int cons_kind, float* out, int* nonfinite,
                     dycon_stream_t stream);
+/* The same two reductions and the FeCL finalize (dycon_fecl_finalize) as ONE launch: the scalar end of the step's loss forward
+ * from the raw accumulators -- sums (16 doubles of dycon_seg_losses_fwd) and fecl_out (4 doubles of dycon_fecl_fwd, may be NULL),
+ * after a data-parallel run has all-reduced them (B, LB, fecl_rows are then the GLOBAL counts).  out[6] as dycon_step_loss. */
+int dycon_step_losses(const double* sums, const double* fecl_out, int B, int LB, long long V, float beta,
+                      double fecl_rows, float lambda_cross, int has_teacher, float l_weight, float cons_weight,
+                      float u_weight, int dice_kind, int cons_kind, float* out, int* nonfinite,
+                      dycon_stream_t stream);
 
 /* ---------------------------------------------------------------- the reference's loss callables, reference semantics
  * The fused pass above takes LOGITS; the reference's own step body instead calls utils/losses.py on PROBABILITIES it computed

@@ -35,21 +35,37 @@ def within_budget(hip, ref32, ref64, what, floor=1e-4):
     np.testing.assert_allclose(hip, ref64, rtol=floor, atol=floor, err_msg=what)
 
 
-def grad_within_budget(got, ref32, ref64, what):
+class FallbackBudget:
+    """How many gradient tensors of ONE network comparison may take the direction-only bound of grad_within_budget (ReLU-decision
+    flips are rare events: tools/bwd_bisect.py found one voxel in one tensor).  A real defect in a layer moves that layer's tensors
+    AND everything upstream of it, so a cap of 2 per net separates the two."""
+
+    def __init__(self, cap=2):
+        self.cap, self.names = cap, []
+
+    def check(self):
+        assert len(self.names) <= self.cap, f"{len(self.names)} gradient tensors needed the direction-only bound (cap {self.cap}): {self.names}"
+
+
+def grad_within_budget(got, ref32, ref64, what, budget=None):
     """A parameter gradient against the fp64 twin.  Tight bound: within 1e-4 of the tensor's scale or 3x the reference's own fp32
     error (two fp32 implementations draw their round-off from the same distribution, not the same value).  Where that fails, the
     difference must be explained by ReLU decisions: a voxel whose pre-activation lies within fp32 round-off of zero (|v| ~ 1e-6) is
     switched on in one fp32 implementation and off in another, and its WHOLE gradient then differs -- tools/bwd_bisect.py traces a
     1e-2 relative difference of a deep-layer gradient to one such voxel (pre-activation -2.05e-6 in double) with every other voxel
-    agreeing to 3e-10.  Such flips leave the direction intact and move the tensor by a few 1e-3 of its norm: bounded below."""
+    agreeing to 3e-10.  Such flips leave the direction intact and move the tensor by a few 1e-3 of its norm: bounded below, and the
+    tensors that take this fallback are COUNTED against `budget` (FallbackBudget: at most 2 per network comparison)."""
     got, ref32, ref64 = got.detach().double().cpu(), ref32.detach().double().cpu(), ref64.detach().double().cpu()
     scale = float(ref64.abs().max())
     e_hip, e_ref = float((got - ref64).abs().max()), float((ref32 - ref64).abs().max())
     rel_l2 = float((got - ref64).norm() / (ref64.norm() + 1e-30))
     cos = float((got * ref64).sum() / (got.norm() * ref64.norm() + 1e-30))
-    print(f"{what}: |hip-ref64| {e_hip:.3e}, reference's own |ref32-ref64| {e_ref:.3e}, scale {scale:.3e}, rel L2 {rel_l2:.2e}, cos {cos:.7f}")
     tight = e_hip <= max(1e-4 * scale, 3 * e_ref) + 1e-9
+    print(f"{what}: |hip-ref64| {e_hip:.3e}, reference's own |ref32-ref64| {e_ref:.3e}, scale {scale:.3e}, rel L2 {rel_l2:.2e}, cos {cos:.7f}"
+          f"{'' if tight else '   <- direction-only bound'}")
     assert tight or (rel_l2 <= 2e-2 and cos >= 0.9998), f"{what}: |hip-ref64| {e_hip:.3e}, |ref32-ref64| {e_ref:.3e}, rel L2 {rel_l2:.2e}, cos {cos:.6f}"
+    if not tight and budget is not None:
+        budget.names.append(what)
 
 
 def build(kind, seed, dtype=torch.float32):
@@ -161,8 +177,10 @@ def test_vnet_dropout3d_masks_vs_oracle():
     leaves64 = {k: p_all[k].double().clone().requires_grad_(True) for k in names}
     _, lo64g, fe64g = ON.vnet_forward(x.double(), {**_double(p_all), **leaves64}, drop5=m5.double(), drop9=m9.double())
     grads64 = dict(zip(names, torch.autograd.grad((lo64g * r1.double()).sum() + (fe64g * r2.double()).sum(), [leaves64[k] for k in names])))
+    fb = FallbackBudget()
     for k in ("block_nine.conv.0.weight", "block_five.conv.6.weight", "block_one.conv.1.weight", "out_conv.weight"):
-        grad_within_budget(eng.g[k], dict(zip(names, grads))[k], grads64[k], k)
+        grad_within_budget(eng.g[k], dict(zip(names, grads))[k], grads64[k], k, fb)
+    fb.check()
 
 
 def test_vnet_batchnorm_dropout3d_masks_vs_oracle():
@@ -198,9 +216,11 @@ def test_vnet_batchnorm_dropout3d_masks_vs_oracle():
     within_budget(logits.cpu().permute(0, 4, 1, 2, 3).numpy(), lo_ref.detach().numpy(), lo64.detach().numpy(), "logits")
     within_budget(feats.cpu().permute(0, 4, 1, 2, 3).numpy(), fe_ref.detach().numpy(), fe64.detach().numpy(), "feats")
     eng.backward(r1.permute(0, 2, 3, 4, 1).contiguous().to(DEV), r2.permute(0, 2, 3, 4, 1).contiguous().to(DEV))
+    fb = FallbackBudget()
     for k in ("block_nine.conv.0.weight", "block_nine.conv.1.weight", "block_five.conv.6.weight", "block_five.conv.7.weight", "out_conv.weight",
               "block_one.conv.0.weight"):
-        grad_within_budget(eng.g[k], gr[k], gr64[k], k)
+        grad_within_budget(eng.g[k], gr[k], gr64[k], k, fb)
+    fb.check()
 
 
 def test_vnet_isles_geometry_vs_oracle():
@@ -234,30 +254,6 @@ def test_pancreas_geometry_vs_oracle(kind):
     assert tuple(feats.shape) == (1, 14, 14, 12, 256)
     within_budget(logits.cpu().permute(0, 4, 1, 2, 3).numpy(), lo_ref.numpy(), lo64.numpy(), "logits")
     within_budget(feats.cpu().permute(0, 4, 1, 2, 3).numpy(), fe_ref.numpy(), fe64.numpy(), "feats")
-
-
-def test_bf16_step_gradient_tracks_fp32_isles_geometry():
-    """One full DyCON step at 112x112x80 (feature_scaler 4, ISLES variants: multi-class Dice, eval-mode teacher) in bf16 and
-    fp32 storage from the same state: the flat gradient arenas agree in direction and size."""
-    from dycon_paper_replication_amd.engine import DropoutSpec
-    from dycon_paper_replication_amd.synthetic import make_batch
-    from dycon_paper_replication_amd.trainer import DyconTrainer, TrainConfig
-    vol, lab, noise = make_batch(5, 2, (112, 112, 80))
-    grads, losses = {}, {}
-    for dt in (torch.float32, torch.bfloat16):
-        cfg = TrainConfig(model="vnet", labeled_bs=1, batch_size=2, dtype=dt, feature_scaler=4, dice_variant="multiclass",
-                          teacher_mode="eval", poly_lr=True, seed=11)
-        tr = DyconTrainer(cfg, DEV)
-        off = DropoutSpec("off")
-        out = tr.step(vol.to(DEV), lab.to(DEV), noise=noise.to(DEV), s_drop=off, t_drop=off)
-        assert not out["skipped"]
-        grads[dt] = tr.flat_g[: tr.n_sgd].clone()
-        losses[dt] = [float(out[k]) for k in ("loss", "ce", "dice", "cons", "fecl", "uncl")]
-    a, b = grads[torch.bfloat16], grads[torch.float32]
-    cos = float((a * b).sum() / (a.norm() * b.norm()))
-    ratio = float(a.norm() / b.norm())
-    assert cos > 0.98 and 0.9 < ratio < 1.1, (cos, ratio)
-    np.testing.assert_allclose(losses[torch.bfloat16], losses[torch.float32], rtol=3e-2, atol=3e-3)
 
 
 @pytest.mark.parametrize("norm", ["none", "batchnorm", "instancenorm"])
@@ -295,8 +291,10 @@ def test_vnet_other_normalizations_vs_oracle(norm):
     leaves64 = {k: p_all[k].double().clone().requires_grad_(True) for k in names}
     _, lo64g, fe64g = ON.vnet_forward(x.double(), {**_double(p_all), **leaves64}, normalization=norm)
     gr64 = dict(zip(names, torch.autograd.grad((lo64g * r1.double()).sum() + (fe64g * r2.double()).sum(), [leaves64[k] for k in names])))
+    fb = FallbackBudget()
     for k in ("block_nine.conv.0.weight", "block_five.conv.0.weight", "block_one.conv.0.weight", "out_conv.weight",
               "block_five_up.conv.0.weight", "block_two_dw.conv.0.weight") + (("block_three.conv.1.weight",) if norm == "batchnorm" else ()):
-        grad_within_budget(eng.g[k], gr[k], gr64[k], k)
+        grad_within_budget(eng.g[k], gr[k], gr64[k], k, fb)
+    fb.check()
     if norm == "batchnorm":      # running statistics updated with momentum 0.1 (nn.BatchNorm3d defaults)
         assert float(bufs["block_one.conv.1.running_mean"].abs().max()) > 0 and int(bufs["block_one.conv.1.num_batches_tracked"]) == 1
