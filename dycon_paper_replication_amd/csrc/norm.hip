@@ -394,11 +394,14 @@ __device__ __forceinline__ void block_reduce_vec(float (&v)[NV], float* sm /* [4
     for (int k = 0; k < NV; ++k) v[k] = sm[k] + sm[NV + k] + sm[2 * NV + k] + sm[3 * NV + k];
 }
 
+// rows per thread of the one-launch norms (template parameter ROWS): 8 x 256 threads = the 2048 rows norm_fused_ok admits; 1 where
+// the level has at most 256 voxels (6^3, 7x7x5)
+
 // SLAB = true: x does not exist yet -- it is the ordered sum of the split-K partial slabs of the convolution that feeds this norm
 // (conv_k3_tile_kernel / conv_gemm_kernel, fp32 [split][row][channel]) plus the bias.  The statistics pass forms it (the same
 // summation order as splitk_finish_kernel), rounds it to T, WRITES it to X (the backward needs the pre-norm tensor) and takes the
 // statistics of the rounded values: bit-identical to finish launch + norm launch, with one launch less on the critical chain.
-template <typename T, int SPAN, int CPG, bool SLAB>
+template <typename T, int SPAN, int CPG, bool SLAB, int NF_ROWS>
 __global__ __launch_bounds__(256) void norm_fused_fwd_kernel(T* __restrict__ X, T* __restrict__ Y, long long V, int C, int G,
                                                              float eps, float* __restrict__ stats, const float* __restrict__ gamma,
                                                              const float* __restrict__ beta, int relu, const T* __restrict__ skip,
@@ -413,15 +416,22 @@ __global__ __launch_bounds__(256) void norm_fused_fwd_kernel(T* __restrict__ X, 
     float acc[2 * SPAN];
 #pragma unroll
     for (int k = 0; k < 2 * SPAN; ++k) acc[k] = 0.f;
-    for (long long v = threadIdx.x; v < V; v += 256) {
+    // The workgroup's slice (V <= 2048 rows x SPAN channels: norm_fused_ok) stays in REGISTERS between the statistics and the apply
+    // pass: every thread requests its NF_ROWS rows up front (fixed trip count, clamped addresses: all loads are in flight together)
+    // and the apply pass re-reads nothing.  The loop over v this replaces made ~7 dependent L2 round trips per pass (11 us for 1.7 MB).
+    // Rows are summed in the order of that loop (masked rows add +0): same statistics bit for bit.
+    Vec16<T> xr[NF_ROWS][NVEC];
+#pragma unroll
+    for (int i = 0; i < NF_ROWS; ++i) {
+        const long long v = threadIdx.x + 256 * i;
+        const long long vc = v < V ? v : V - 1;
 #pragma unroll
         for (int q = 0; q < NVEC; ++q) {
-            Vec16<T> x;
             if (SLAB) {
                 // slabs are span-major (conv_gemm / conv_k3_tile with a deferred finish): [split][8-channel span][row][8] fp32, so the
                 // rows of this workgroup's span are one contiguous 32-byte-per-row run in every slab (VN == 8 here: bf16 only)
                 const long long Mrows = MN / C;
-                const long long off = ((long long)((c0 + q * VN) >> 3) * Mrows + (long long)n * V + v) * 8;
+                const long long off = ((long long)((c0 + q * VN) >> 3) * Mrows + (long long)n * V + vc) * 8;
                 float f[VN];
 #pragma unroll
                 for (int k = 0; k < VN; ++k) f[k] = cbias ? cbias[c0 + q * VN + k] : 0.f;
@@ -433,14 +443,20 @@ __global__ __launch_bounds__(256) void norm_fused_fwd_kernel(T* __restrict__ X, 
                     }
                 }
 #pragma unroll
-                for (int k = 0; k < VN; ++k) x.set(k, f[k]);
-                st16(xp + v * C + q * VN, x);
+                for (int k = 0; k < VN; ++k) xr[i][q].set(k, f[k]);
+                if (v < V) st16(xp + v * C + q * VN, xr[i][q]);
             } else {
-                x = ld16(xp + v * C + q * VN);
+                xr[i][q] = ld16(xp + vc * C + q * VN);
             }
-#pragma unroll
-            for (int k = 0; k < VN; ++k) { const float f = x.get(k); acc[q * VN + k] += f; acc[SPAN + q * VN + k] += f * f; }
         }
+    }
+#pragma unroll
+    for (int i = 0; i < NF_ROWS; ++i) {
+        const bool ok = (long long)threadIdx.x + 256 * i < V;
+#pragma unroll
+        for (int q = 0; q < NVEC; ++q)
+#pragma unroll
+            for (int k = 0; k < VN; ++k) { const float f = ok ? xr[i][q].get(k) : 0.f; acc[q * VN + k] += f; acc[SPAN + q * VN + k] += f * f; }
     }
     block_reduce_vec<2 * SPAN>(acc, sm);
     // per-channel scale / shift (every thread computes all SPAN of them: cheap, avoids another LDS round trip)
@@ -476,26 +492,37 @@ __global__ __launch_bounds__(256) void norm_fused_fwd_kernel(T* __restrict__ X, 
     }
     T* yp = Y + (long long)n * V * C + c0;
     const T* sp = skip ? skip + (long long)n * V * C + c0 : nullptr;
-    for (long long v = threadIdx.x; v < V; v += 256) {
+    Vec16<T> sr[NF_ROWS][NVEC];
+    if (sp) {
 #pragma unroll
-        for (int q = 0; q < NVEC; ++q) {
-            const Vec16<T> x = ld16(xp + v * C + q * VN);
-            Vec16<T> s, y;
-            if (sp) s = ld16(sp + v * C + q * VN);
+        for (int i = 0; i < NF_ROWS; ++i) {
+            const long long v = threadIdx.x + 256 * i, vc = v < V ? v : V - 1;
 #pragma unroll
-            for (int k = 0; k < VN; ++k) {
-                float f = x.get(k) * sc[q * VN + k] + sh[q * VN + k];
-                if (relu) f = f < 0.f ? 0.f : f;
-                f *= cs[q * VN + k];
-                if (sp) f += s.get(k);
-                y.set(k, f);
+            for (int q = 0; q < NVEC; ++q) sr[i][q] = ld16(sp + vc * C + q * VN);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NF_ROWS; ++i) {
+        const long long v = threadIdx.x + 256 * i;
+        if (v < V) {
+#pragma unroll
+            for (int q = 0; q < NVEC; ++q) {
+                Vec16<T> y;
+#pragma unroll
+                for (int k = 0; k < VN; ++k) {
+                    float f = xr[i][q].get(k) * sc[q * VN + k] + sh[q * VN + k];
+                    if (relu) f = f < 0.f ? 0.f : f;
+                    f *= cs[q * VN + k];
+                    if (sp) f += sr[i][q].get(k);
+                    y.set(k, f);
+                }
+                st16(yp + v * C + q * VN, y);
             }
-            st16(yp + v * C + q * VN, y);
         }
     }
 }
 
-template <typename T, int SPAN, int CPG>
+template <typename T, int SPAN, int CPG, int NF_ROWS>
 __global__ __launch_bounds__(256) void norm_fused_bwd_kernel(const T* __restrict__ X, const T* __restrict__ GY, T* __restrict__ GX,
                                                              long long V, int C, int G, const float* __restrict__ stats,
                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -520,18 +547,27 @@ __global__ __launch_bounds__(256) void norm_fused_bwd_kernel(const T* __restrict
     float acc[2 * SPAN];
 #pragma unroll
     for (int k = 0; k < 2 * SPAN; ++k) acc[k] = 0.f;
-    for (long long v = threadIdx.x; v < V; v += 256) {
+    // register-resident as norm_fused_fwd_kernel: both operands of every row are requested up front and read ONCE
+    Vec16<T> xr[NF_ROWS][NVEC], gr[NF_ROWS][NVEC];
+#pragma unroll
+    for (int i = 0; i < NF_ROWS; ++i) {
+        const long long v = threadIdx.x + 256 * i, vc = v < V ? v : V - 1;
+#pragma unroll
+        for (int q = 0; q < NVEC; ++q) { xr[i][q] = ld16(xp + vc * C + q * VN); gr[i][q] = ld16(gp + vc * C + q * VN); }
+    }
+#pragma unroll
+    for (int i = 0; i < NF_ROWS; ++i) {
+        const bool ok = (long long)threadIdx.x + 256 * i < V;
 #pragma unroll
         for (int q = 0; q < NVEC; ++q) {
-            const Vec16<T> x = ld16(xp + v * C + q * VN), gv = ld16(gp + v * C + q * VN);
 #pragma unroll
             for (int k = 0; k < VN; ++k) {
                 const int j = q * VN + k;
-                const float xh = (x.get(k) - mean[j]) * rstd[j];
-                float g = gv.get(k) * cs[j];
-                if (relu && !(gm[j] * xh + bt[j] > 0.f)) g = 0.f;
+                const float xh = (xr[i][q].get(k) - mean[j]) * rstd[j];
+                float g = gr[i][q].get(k) * cs[j];
+                if ((relu && !(gm[j] * xh + bt[j] > 0.f)) || !ok) g = 0.f;
                 acc[j] += g;
-                acc[SPAN + j] += g * xh;
+                acc[SPAN + j] += ok ? g * xh : 0.f;
             }
         }
     }
@@ -557,20 +593,23 @@ __global__ __launch_bounds__(256) void norm_fused_bwd_kernel(const T* __restrict
         Bq[k] = bq * inv_cnt;
     }
     T* op = GX + (long long)n * V * C + c0;
-    for (long long v = threadIdx.x; v < V; v += 256) {
 #pragma unroll
-        for (int q = 0; q < NVEC; ++q) {
-            const Vec16<T> x = ld16(xp + v * C + q * VN), gv = ld16(gp + v * C + q * VN);
-            Vec16<T> o;
+    for (int i = 0; i < NF_ROWS; ++i) {
+        const long long v = threadIdx.x + 256 * i;
+        if (v < V) {
 #pragma unroll
-            for (int k = 0; k < VN; ++k) {
-                const int j = q * VN + k;
-                const float xh = (x.get(k) - mean[j]) * rstd[j];
-                float g = gv.get(k) * cs[j];
-                if (relu && !(gm[j] * xh + bt[j] > 0.f)) g = 0.f;
-                o.set(k, rstd[j] * (gm[j] * g - (A[j] + xh * Bq[j])));
+            for (int q = 0; q < NVEC; ++q) {
+                Vec16<T> o;
+#pragma unroll
+                for (int k = 0; k < VN; ++k) {
+                    const int j = q * VN + k;
+                    const float xh = (xr[i][q].get(k) - mean[j]) * rstd[j];
+                    float g = gr[i][q].get(k) * cs[j];
+                    if (relu && !(gm[j] * xh + bt[j] > 0.f)) g = 0.f;
+                    o.set(k, rstd[j] * (gm[j] * g - (A[j] + xh * Bq[j])));
+                }
+                st16(op + v * C + q * VN, o);
             }
-            st16(op + v * C + q * VN, o);
         }
     }
 }
@@ -621,10 +660,12 @@ extern "C" int dycon_norm_fwd_slab(const float* slab, int splits, const float* c
     const int cpg = C / G, span = cpg > 8 ? cpg : 8;
     const long long MN = (long long)Nb * V * C;
     dim3 grid(C / span, Nb);
-#define DYCON_NFS(SP, CP) norm_fused_fwd_kernel<bf16, SP, CP, true><<<grid, 256, 0, stream>>>((bf16*)x_out, (bf16*)y, V, C, G, eps, stats, gamma, beta, relu, (const bf16*)skip, chan_scale, nullptr, nullptr, 0.f, slab, splits, MN, conv_bias)
+#define DYCON_NFS_(SP, CP, RW) norm_fused_fwd_kernel<bf16, SP, CP, true, RW><<<grid, 256, 0, stream>>>((bf16*)x_out, (bf16*)y, V, C, G, eps, stats, gamma, beta, relu, (const bf16*)skip, chan_scale, nullptr, nullptr, 0.f, slab, splits, MN, conv_bias)
+#define DYCON_NFS(SP, CP) do { if (V <= 256) DYCON_NFS_(SP, CP, 1); else DYCON_NFS_(SP, CP, 8); } while (0)
     if (cpg == 1) DYCON_NFS(8, 1); else if (cpg == 2) DYCON_NFS(8, 2); else if (cpg == 4) DYCON_NFS(8, 4);
     else if (cpg == 8) DYCON_NFS(8, 8); else DYCON_NFS(16, 16);
 #undef DYCON_NFS
+#undef DYCON_NFS_
     DYCON_LAUNCH_CHECK();
     return DYCON_OK;
 }
@@ -658,7 +699,8 @@ extern "C" int dycon_norm_fwd(const void* x, void* y, int dtype, int Nb, long lo
         const int VN = dtype == DYCON_BF16 ? 8 : 4, cpg = C / G;
         const int span = cpg > VN ? cpg : VN;
         dim3 grid(C / span, Nb);
-#define DYCON_NF(TT, SP, CP) norm_fused_fwd_kernel<TT, SP, CP, false><<<grid, 256, 0, stream>>>((TT*)const_cast<void*>(x), (TT*)y, V, C, G, eps, stats, gamma, beta, relu, (const TT*)skip, chan_scale, running_mean, running_var, momentum, nullptr, 0, 0, nullptr)
+#define DYCON_NF_(TT, SP, CP, RW) norm_fused_fwd_kernel<TT, SP, CP, false, RW><<<grid, 256, 0, stream>>>((TT*)const_cast<void*>(x), (TT*)y, V, C, G, eps, stats, gamma, beta, relu, (const TT*)skip, chan_scale, running_mean, running_var, momentum, nullptr, 0, 0, nullptr)
+#define DYCON_NF(TT, SP, CP) do { if (V <= 256) DYCON_NF_(TT, SP, CP, 1); else DYCON_NF_(TT, SP, CP, 8); } while (0)
         if (dtype == DYCON_BF16) {
             if (cpg == 1) DYCON_NF(bf16, 8, 1); else if (cpg == 2) DYCON_NF(bf16, 8, 2); else if (cpg == 4) DYCON_NF(bf16, 8, 4);
             else if (cpg == 8) DYCON_NF(bf16, 8, 8); else DYCON_NF(bf16, 16, 16);
@@ -667,6 +709,7 @@ extern "C" int dycon_norm_fwd(const void* x, void* y, int dtype, int Nb, long lo
             else if (cpg == 8) DYCON_NF(float, 8, 8); else DYCON_NF(float, 16, 16);
         }
 #undef DYCON_NF
+#undef DYCON_NF_
         DYCON_LAUNCH_CHECK();
         return DYCON_OK;
     }
@@ -764,7 +807,8 @@ extern "C" int dycon_norm_bwd_ex(const void* src, int from_y, const void* gy, vo
         const int span = cpg > VN ? cpg : VN;
         const bool want = dgamma || dbeta;
         dim3 grid(C / span, Nb);
-#define DYCON_NB(TT, SP, CP) norm_fused_bwd_kernel<TT, SP, CP><<<grid, 256, 0, stream>>>((const TT*)src, (const TT*)gy, (TT*)gx, V, C, G, stats, gamma, beta, relu, chan_scale, want ? workspace : nullptr)
+#define DYCON_NB_(TT, SP, CP, RW) norm_fused_bwd_kernel<TT, SP, CP, RW><<<grid, 256, 0, stream>>>((const TT*)src, (const TT*)gy, (TT*)gx, V, C, G, stats, gamma, beta, relu, chan_scale, want ? workspace : nullptr)
+#define DYCON_NB(TT, SP, CP) do { if (V <= 256) DYCON_NB_(TT, SP, CP, 1); else DYCON_NB_(TT, SP, CP, 8); } while (0)
         if (dtype == DYCON_BF16) {
             if (cpg == 1) DYCON_NB(bf16, 8, 1); else if (cpg == 2) DYCON_NB(bf16, 8, 2); else if (cpg == 4) DYCON_NB(bf16, 8, 4);
             else if (cpg == 8) DYCON_NB(bf16, 8, 8); else DYCON_NB(bf16, 16, 16);
@@ -773,6 +817,7 @@ extern "C" int dycon_norm_bwd_ex(const void* src, int from_y, const void* gy, vo
             else if (cpg == 8) DYCON_NB(float, 8, 8); else DYCON_NB(float, 16, 16);
         }
 #undef DYCON_NB
+#undef DYCON_NB_
         DYCON_LAUNCH_CHECK();
         if (want && !defer_dparams) {     // deferred: the caller sums them (dycon_norm_sum_dparams), possibly on another stream
             norm_sum_dparams_kernel<<<cdiv(C, 256), 256, 0, stream>>>(workspace, Nb, C, dgamma, dbeta);

@@ -194,6 +194,7 @@ class DyconTrainer:
             self.buckets = [(by_off[lo], lo, hi) for lo, hi in zip(cuts[:-1], cuts[1:])]
             self._bucket_of = {name: (lo, hi) for name, lo, hi in self.buckets}
             self._pending = []
+            self.comm = torch.cuda.Stream(device=self.device)
             self.s_eng.on_param_grads = self._on_param_grads
 
     def _mark(self, tag, stream=None):
@@ -210,18 +211,20 @@ class DyconTrainer:
         if rng is not None:
             # The bucket holds gradients written on up to three streams: conv weights / biases (weight-gradient stream), norm affine
             # parameters (main) and the projection head's parameters (feature stream, whose backward was enqueued first).  The
-            # collective is ordered after the stream it is issued from: make that stream wait for the other two.
+            # collective is issued from a FOURTH stream that waits for those three: the data-gradient chain on main never waits for
+            # the weight-gradient stream in mid-backward (it did when the collective was ordered after main: that wait, at four
+            # points of the backward, was most of the 0.3 ms/step the exchange path cost a rank besides wire time).
             others = [o for o in (self._main, self.feat, self.s_eng.wgrad_stream) if o is not None]
             evs = [torch.cuda.Event() for _ in others]
             view = self.flat_g[rng[0]:rng[1]]
+            comm = self.comm
 
             def issue():
-                cur = torch.cuda.current_stream()     # the stream torch.distributed orders the collective after (the weight-gradient
-                for o, ev in zip(others, evs):        # section redirects only this package's launches)
-                    if o != cur:
-                        ev.record(o)
-                        cur.wait_event(ev)
-                self._pending.append(torch.distributed.all_reduce(view, group=self.pg, async_op=True))
+                for o, ev in zip(others, evs):
+                    ev.record(o)
+                    comm.wait_event(ev)
+                with torch.cuda.stream(comm):         # torch.distributed orders the collective after the current stream
+                    self._pending.append(torch.distributed.all_reduce(view, group=self.pg, async_op=True))
             ops.rec(issue)
 
     # ------------------------------------------------------------------ schedules (host scalars)
