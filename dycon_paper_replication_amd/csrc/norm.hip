@@ -567,7 +567,7 @@ __global__ __launch_bounds__(256) void norm_fused_bwd_kernel(const T* __restrict
                 float g = gr[i][q].get(k) * cs[j];
                 if ((relu && !(gm[j] * xh + bt[j] > 0.f)) || !ok) g = 0.f;
                 acc[j] += g;
-                acc[SPAN + j] += ok ? g * xh : 0.f;
+                acc[SPAN + j] += g * xh;              // (g = 0 on masked rows; one fma, as in the loop this replaces: same bits)
             }
         }
     }

@@ -147,11 +147,15 @@ def test_conv_accumulate():
     close(nc(e.G[id(xd)]), xr.grad + nc(prior), 1e-4, 1e-5)
 
 
-@pytest.mark.parametrize("kind,C", [("gn", 32), ("gn", 16), ("in", 16), ("in", 48), ("bn", 512)])
+# spatial sizes: 120 voxels (one row per thread of the one-launch kernels), 12^3 = 1728 and 8^3 = 512 (the register-resident form with
+# 8 rows per thread, partly masked), 14 x 14 x 13 = 2548 (past the one-launch limit: statistics / finalize / apply launches)
+@pytest.mark.parametrize("kind,C,sp", [("gn", 32, (4, 6, 5)), ("gn", 16, (4, 6, 5)), ("in", 16, (4, 6, 5)), ("in", 48, (4, 6, 5)), ("bn", 512, (4, 6, 5)),
+                                       ("gn", 128, (12, 12, 12)), ("gn", 64, (8, 8, 8)), ("in", 64, (8, 8, 8)), ("gn", 256, (7, 7, 5)),
+                                       ("in", 128, (12, 12, 12)), ("gn", 64, (14, 14, 13))])
 @pytest.mark.parametrize("mode", ["relu", "skip", "norelu"])
-def test_norm(kind, C, mode):
+def test_norm(kind, C, sp, mode):
     rng = np.random.default_rng(C)
-    B, sp = 2, (4, 6, 5)
+    B = 2
     z = T((rng.standard_normal((B, C) + sp) * 1.5 + 0.3).astype(np.float32))
     gamma = T((1 + 0.2 * rng.standard_normal(C)).astype(np.float32))
     beta = T((0.2 * rng.standard_normal(C)).astype(np.float32))
@@ -189,7 +193,8 @@ def test_norm(kind, C, mode):
         close(nc(e.G[id(sd)]), gy, 0, 0, "gskip")
     if mode == "norelu" and kind != "in":
         # without ReLU the op is invertible: the backward may recover xhat from y (from_y = 1)
-        Nb, G, V = (1, C, B * 120) if kind == "bn" else (B, 16, 120)
+        nvox = sp[0] * sp[1] * sp[2]
+        Nb, G, V = (1, C, B * nvox) if kind == "bn" else (B, 16, nvox)
         stats = ops.norm_stats(zd, Nb, V, C, G)
         gz2 = ops.norm_bwd(ycopy, True, nd(gy), stats, Nb, V, C, G, e.p["n.weight"], e.p["n.bias"], False)
         close(nc(gz2), zr.grad, 2e-3, 2e-4, "gz from y")
