@@ -1195,6 +1195,272 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_k3_p32_kernel(const bf16* __r
 #endif
 }
 
+// The same kernel on v_mfma_f32_32x32x16_bf16: conv_k3_p32_kernel's tap loop is vector-ISSUE bound (stamps: ~215
+// issue cycles per tap against 128 of MFMA at one wave per SIMD), and a 16x16x32 MFMA holds the SIMD's vector issue for 8 of its 16
+// cycles, a 32x32x16 for 8 of its 32 (MI355X_MICROARCH.md, cycle constants): per tap a wave issues 2 (4) MFMAs instead of 4 (8) for
+// the same 32 output channels x 32 (64) voxels, with the same number of ds_read_b128 (one weight and one activation fragment per
+// k-step of 16 channels).  Output tile = 32 channels x 32 voxels (4 y rows x 8 x): one accumulator of 16 registers per 32 voxels.
+// Differences to conv_k3_p32_kernel: fragment order of the weights in LDS (re-ordered in the prologue copy), rotation of the 8-channel
+// chunks inside a voxel's 64 bytes (conflict-free for the 32-voxel read pattern), epilogue lane map.  Same results bit for bit is NOT
+// expected (the k order inside a tap differs: two k-steps of 16 instead of one of 32): tested element-wise like every conv kernel.
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+template <int NW, bool STATS>
+__global__ __launch_bounds__(64 * NW, 1) void conv_k3_p32x_kernel(const bf16* __restrict__ X, const bf16* __restrict__ Wf,
+                                                             const float* __restrict__ bias, bf16* __restrict__ Y, int B, int D,
+                                                             int H, int W, int tilesZ, int tilesY, int tilesX, int nTiles,
+                                                             float* __restrict__ stat_part) {
+    __shared__ __attribute__((aligned(16))) unsigned short Xh[2 * P32_XH];
+    __shared__ __attribute__((aligned(16))) unsigned short Bs[P32_BS];
+    int tile, t_end, t_stride;
+    xcd_tile_range(nTiles, tile, t_end, t_stride);
+    // stat_part: per-(sample, workgroup) {sum, sum of squares} of the STORED (bf16) outputs per channel, [B][gridDim.x][32][2] -- the
+    // statistics pass of the normalisation that follows (norm_partial_kernel) then does not run: a persistent workgroup adds up its ~7
+    // tiles in registers and writes one row per sample it touched (rows of the other samples: zero)
+    if (STATS && threadIdx.x < 64)
+        for (int n = 0; n < B; ++n) stat_part[((long long)n * gridDim.x + blockIdx.x) * 64 + threadIdx.x] = 0.f;
+    if (tile >= t_end) return;                               // (uniform)
+    constexpr int NTHR = 64 * NW, YH = NW / 4, NA = 2 / YH;   // y-halves of a z-slice over the waves; 32-voxel accumulators (4 y rows x 8) per wave
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r5 = lane & 31, hl = lane >> 5;                // MFMA 32x32x16: column (voxel) r5, k half hl
+    const int zs = wave & 3, yh = wave >> 2;                 // this wave: z-slice zs, y rows [8 / YH * yh, ...)
+#ifdef P32_STAMP
+    unsigned long long seg[6] = {0, 0, 0, 0, 0, 0};
+    P32_T(k0);
+#endif
+    // weights: every piece of this thread in flight at once.  The packed order (dycon_pack_bfrag: [tap][16-column tile][lane of the
+    // 16x16x32 fragment][8]) is re-ordered on the way into LDS into the A fragments of the 32x32x16 instruction, [tap][k-step of 16
+    // channels][lane][8] with lane = (k half hl, output channel r5): a permutation of whole 16-byte pieces
+    constexpr int NWP = P32_BS / 8;                          // 3456 pieces of 16 B
+    constexpr int NWS = (NWP + NTHR - 1) / NTHR;             // 14 (7) per thread
+    uint4 wst[NWS];
+#pragma unroll
+    for (int it = 0; it < NWS; ++it) {
+        const int e = min((int)threadIdx.x + NTHR * it, NWP - 1);
+        const int tp = e >> 7, ks = (e >> 6) & 1, hh = (e >> 5) & 1, rr = e & 31;
+        const int src = tp * 128 + (rr >> 4) * 64 + ((2 * ks + hh) << 4) + (rr & 15);
+        wst[it] = *reinterpret_cast<const uint4*>(Wf + (long long)src * 8);
+    }
+
+    // Activation fragments (the MFMA's B operand, 16 channels x 32 voxels): wave w owns z-slice zs, accumulator a = y rows 4a .. 4a+3
+    // of its half; k-step ks of tap t reads the 8-channel chunk c = 2 ks + hl of voxel (y, x + dx), which sits at rotated position
+    // (c + ((x + dx) >> 1)) & 3 of that voxel's 64 bytes: the 16 lanes ds_read_b128 services together then hit 64 distinct banks
+    // (lane groups {0-3, 12-15, 20-27} ...: per 16-bank window the four voxels have x = w, w + 2, w + 4, w + 6 modulo 8).
+    constexpr int ASTEP = 4 * P32_RP * P32_VS;
+    int abase[3][2];
+    {
+        const int vb = ((zs * CL_HY + 4 * NA * yh + (r5 >> 3)) * P32_RP + (r5 & 7)) * P32_VS;
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) abase[dx][ks] = vb + dx * P32_VS + 8 * ((2 * ks + hl + (((r5 & 7) + dx) >> 1)) & 3);
+    }
+    const int bbase = lane * 8;
+
+    constexpr int NPC = CL_NH * 4;                           // 2400 halo pieces of 16 B
+    constexpr int NST = (NPC + NTHR - 1) / NTHR;             // per thread (10 or 5; pieces past the end duplicate the last one)
+    int rel[NST], lofs[NST];
+    unsigned need[NST];
+#pragma unroll
+    for (int it = 0; it < NST; ++it) {
+        const int e = min((int)threadIdx.x + NTHR * it, NPC - 1);
+        const int hv = e >> 2, pc = e & 3;
+        const int hx = hv % CL_HX, hy = (hv / CL_HX) % CL_HY, hz = hv / (CL_HX * CL_HY);
+        rel[it] = (((hz - 1) * H + (hy - 1)) * W + (hx - 1)) * 32 + 8 * pc;
+        lofs[it] = ((hv / CL_HX) * P32_RP + hx) * P32_VS + 8 * ((pc + (hx >> 1)) & 3);
+        need[it] = (1u << hz) | (1u << (6 + hy)) | (1u << (16 + hx));
+    }
+    // output (C/D of 32x32x16): lane (r5, hl) holds, for its voxel r5 of each accumulator, channels 8 g + 4 hl + i  (register 4 g + i)
+    const int obase = ((zs * H + 4 * NA * yh + (r5 >> 3)) * W + (r5 & 7)) * 32 + 4 * hl;
+    const int ostep = 4 * W * 32;
+    float bv[4][4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) bv[g][i] = bias ? bias[8 * g + 4 * hl + i] : 0.f;
+
+    auto geometry = [&](int t, P32Geo& g) {                  // scalar: tile index -> origin and validity mask (clamped past the end)
+        t = min(t, t_end - 1);
+        const int tx = t % tilesX; t /= tilesX;
+        const int ty = t % tilesY; t /= tilesY;
+        const int tz = t % tilesZ;
+        const int b = t / tilesZ;
+        g.z0 = tz * CL_TZ; g.y0 = ty * CL_TY; g.x0 = tx * CL_TX;
+        g.org = ((((long long)b * D + g.z0) * H + g.y0) * W + g.x0) * 32;
+        g.b = b;
+        // valid halo coordinates h: 0 <= c0 + h - 1 < extent  <=>  h in [max(0, 1 - c0), min(n, extent - c0 + 1))
+        auto bits = [](int c0, int extent, int n) {
+            const int lo = c0 >= 1 ? 0 : 1, hi = min(n, extent - c0 + 1);
+            return ((1u << hi) - 1u) & ~((1u << lo) - 1u);
+        };
+        g.mask = bits(g.z0, D, CL_HZ) | (bits(g.y0, H, CL_HY) << 6) | (bits(g.x0, W, CL_HX) << 16);
+    };
+    // Halo loads are UNCONDITIONAL: a piece outside the volume reads the tile's origin voxel instead (a valid address) and is
+    // zeroed when it is written to LDS, so every wave issues exactly NST loads per tile (counted vmcnt waits)
+    auto load_piece = [&](const P32Geo& g, int it, uint4 (&stg)[NST]) {
+        const bool in = (g.mask & need[it]) == need[it];
+        stg[it] = *reinterpret_cast<const uint4*>(X + g.org + (in ? rel[it] : 0));
+    };
+    auto store_piece = [&](const P32Geo& g, int it, const uint4 (&stg)[NST], unsigned short* img) {
+        const bool in = (g.mask & need[it]) == need[it];
+        uint4 v = stg[it];
+        if (!in) v = make_uint4(0, 0, 0, 0);
+        *reinterpret_cast<uint4*>(img + lofs[it]) = v;
+    };
+
+    float st1[4][4], st2[4][4];                              // this lane's channels 8 g + 4 hl + i, summed over its voxels of the current sample
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) st1[g][i] = st2[g][i] = 0.f;
+    int stat_b = -1;
+    __shared__ float sred[NW * 64];
+    auto flush_stats = [&](int bsample) {                    // uniform call: all threads, between two tiles
+        __syncthreads();
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float a = st1[g][i], q2 = st2[g][i];
+#pragma unroll
+                for (int o = 1; o < 32; o <<= 1) { a += __shfl_xor(a, o, 64); q2 += __shfl_xor(q2, o, 64); }
+                if (r5 == 0) { sred[(wave * 32 + 8 * g + 4 * hl + i) * 2] = a; sred[(wave * 32 + 8 * g + 4 * hl + i) * 2 + 1] = q2; }
+                st1[g][i] = st2[g][i] = 0.f;
+            }
+        __syncthreads();
+        if (threadIdx.x < 64) {
+            float v = 0.f;
+            for (int w = 0; w < NW; ++w) v += sred[w * 64 + threadIdx.x];
+            stat_part[((long long)bsample * gridDim.x + blockIdx.x) * 64 + threadIdx.x] = v;
+        }
+        __syncthreads();
+    };
+
+    // One tile.  Halo pieces of the two tiles ahead travel in two register sets: set `ld` receives tile n+2 during taps 0..9 (one
+    // piece per tap), set `st` -- requested a whole tile ago -- is written into the other image during taps 10..19.  Each piece
+    // is pinned inside its tap (sched_barrier), so that its address arithmetic, its load issue or LDS write fills the
+    // vector-issue slots the tap's 8 MFMAs leave free: with one wave per SIMD nothing else would.
+    auto one_tile = [&](int cur, const P32Geo& gcur, const P32Geo& gst, const uint4 (&st)[NST], P32Geo& gld, uint4 (&ld)[NST], int buf) {
+        P32_T(t0);
+        const unsigned short* xh = Xh + buf * P32_XH;
+        unsigned short* xo = Xh + (buf ^ 1) * P32_XH;
+        geometry(cur + 2 * t_stride, gld);                   // (past the end: the last tile again -- loaded and written, never used)
+        f32x16 acc[NA];
+#pragma unroll
+        for (int a = 0; a < NA; ++a)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[a][i] = 0.f;
+        constexpr int LA = P32_LA, RING = P32_LA + 1;        // fragments of tap t+LA are requested before the MFMAs of tap t
+        bf16x8 xfr[RING][2][NA], wfr[RING][2];
+        auto fetch = [&](int n) {
+            const int imm = ((n / 9) * CL_HY + (n / 3) % 3) * P32_RP * P32_VS;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+                for (int a = 0; a < NA; ++a)
+                    xfr[n % RING][ks][a] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(xh + abase[n % 3][ks] + imm + a * ASTEP));
+                wfr[n % RING][ks] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(Bs + bbase + (n * 2 + ks) * 512));
+            }
+        };
+#pragma unroll
+        for (int n = 0; n < LA; ++n) fetch(n);
+#pragma unroll
+        for (int t = 0; t < 27; ++t) {
+            if (t + LA < 27) fetch(t + LA);
+            if (t < NST) load_piece(gld, t, ld);
+            else if (t < 2 * NST) store_piece(gst, t - NST, st, xo);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int a = 0; a < NA; ++a)     // transposed: D[cout][voxel r5] += W[cout][16 channels] . X[16 channels][voxel]
+                    acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wfr[t % RING][ks], xfr[t % RING][ks][a], acc[a], 0, 0, 0);
+#if P32_SGB      // ask for MFMA / LDS reads / VALU in turn: an in-order wave hides other work only in the issue cycles an MFMA leaves free
+#pragma unroll
+            for (int gq = 0; gq < 2; ++gq) {                 // per tap: 2 NA MFMAs, 2 NA + 2 fragment reads
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 2 * P32_SGB, 0);
+            }
+            if (NA == 2) {
+#pragma unroll
+                for (int gq = 0; gq < 2; ++gq) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 2 * P32_SGB, 0);
+                }
+            }
+#endif
+#if P32_PIN
+            if (t < 2 * NST) __builtin_amdgcn_sched_barrier(0);
+#endif
+        }
+        P32_T(t4);
+        {
+            bf16* yb = Y + gcur.org + obase;
+            const bool zok = gcur.z0 + zs < D, xok = gcur.x0 + (r5 & 7) < W;
+#pragma unroll
+            for (int a = 0; a < NA; ++a) {
+                if (zok && xok && gcur.y0 + 4 * (NA * yh + a) + (r5 >> 3) < H) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const unsigned lo = pack_bf16x2(acc[a][4 * g] + bv[g][0], acc[a][4 * g + 1] + bv[g][1]);
+                        const unsigned hi = pack_bf16x2(acc[a][4 * g + 2] + bv[g][2], acc[a][4 * g + 3] + bv[g][3]);
+                        st8_untracked(yb + a * ostep + 8 * g, lo, hi);
+                        if (STATS) {          // (uniform) statistics of the values as stored
+                            const float v0 = __uint_as_float(lo << 16), v1 = __uint_as_float(lo & 0xffff0000u);
+                            const float v2 = __uint_as_float(hi << 16), v3 = __uint_as_float(hi & 0xffff0000u);
+                            st1[g][0] += v0; st2[g][0] += v0 * v0; st1[g][1] += v1; st2[g][1] += v1 * v1;
+                            st1[g][2] += v2; st2[g][2] += v2 * v2; st1[g][3] += v3; st2[g][3] += v3 * v3;
+                        }
+                    }
+                }
+            }
+        }
+        P32_T(t5);
+        __syncthreads();                                     // this tile's image consumed, the next one complete
+        P32_T(t6);
+#ifdef P32_STAMP
+        seg[0] += t4 - t0; seg[3] += t5 - t4; seg[4] += t6 - t5;
+#endif
+    };
+
+    uint4 sa[NST], sb[NST];
+    P32Geo g0, g1, g2;
+    geometry(tile, g0);
+#pragma unroll
+    for (int it = 0; it < NST; ++it) load_piece(g0, it, sa);
+    geometry(tile + t_stride, g1);
+#pragma unroll
+    for (int it = 0; it < NST; ++it) load_piece(g1, it, sb);
+#pragma unroll
+    for (int it = 0; it < NWS; ++it)
+        if ((int)threadIdx.x + NTHR * it < NWP) *reinterpret_cast<uint4*>(Bs + (threadIdx.x + NTHR * it) * 8) = wst[it];
+#pragma unroll
+    for (int it = 0; it < NST; ++it) store_piece(g0, it, sa, Xh);
+    __syncthreads();
+#ifdef P32_STAMP
+    P32_T(k1);
+#endif
+    for (; tile < t_end; tile += 2 * t_stride) {             // tile j of this workgroup's sequence: image j % 2, store set (j+1) % 2
+        if (STATS && g0.b != stat_b) { if (stat_b >= 0) flush_stats(stat_b); stat_b = g0.b; }
+        one_tile(tile, g0, g1, sb, g2, sa, 0);               // computes g0, writes g1's halo (sb), requests g2 into sa
+        if (tile + t_stride >= t_end) break;                 // (uniform)
+        if (STATS && g1.b != stat_b) { flush_stats(stat_b); stat_b = g1.b; }
+        one_tile(tile + t_stride, g1, g2, sa, g0, sb, 1);    // computes g1, writes g2's halo (sa), requests the next g0 into sb
+        g1 = g0;                                             // rotate: the tile just requested is the one after the next
+        g0 = g2;
+        // after the swap: g0 = the tile to compute, whose halo is in image 0 -- its data travelled in sa; g1 = requested into sb
+    }
+    if (STATS && stat_b >= 0) flush_stats(stat_b);
+#ifdef P32_STAMP
+    P32_T(k2);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        for (int i = 0; i < 6; ++i) p32_stamps[i] = seg[i];
+        p32_stamps[6] = k1 - k0;
+        p32_stamps[7] = k2 - k1;
+    }
+#endif
+}
+
 // First layer (ONE input channel -> 16 * NT): K = 27 taps, padded to a single 32-wide k-step whose A fragment is gathered
 // from a 1.2 KB scalar halo image (8 ds_read_u16 per lane and m-tile).  One MFMA per 16 voxels and n-tile: the kernel is a
 // pure HBM stream of its output (2 B in, 32 * NT B out per voxel).  wfrag = dycon_pack_bfrag(T = 27, Cin = 1).
@@ -2847,9 +3113,15 @@ extern "C" int dycon_conv_gemm_ex(const void* x, const void* wfrag, const float*
         if (p32_on && Cin == 32 && Cout == 32 && !accumulate && nTiles >= 1024) {
             const int per_xcd = min(cdiv(nTiles, 8), 32);
             static const long long p32_nw = env_ll("DYCON_P32_WAVES", 8);
-#define DYCON_P32(NWV, STV) conv_k3_p32_kernel<NWV, STV><<<8 * per_xcd, 64 * NWV, 0, stream>>>((const bf16*)x, (const bf16*)wfrag, bias, (bf16*)y, B, Di, Hi, Wi, tz, ty, tx, nTiles, g_stat_part)
-            if (p32_nw == 8) { if (g_stat_part) DYCON_P32(8, true); else DYCON_P32(8, false); }
-            else { if (g_stat_part) DYCON_P32(4, true); else DYCON_P32(4, false); }
+            static const bool p32x = env_ll("DYCON_P32X", 1) != 0;     // 1: the 32x32x16 MFMA form (conv_k3_p32x_kernel)
+#define DYCON_P32(KRN, NWV, STV) KRN<NWV, STV><<<8 * per_xcd, 64 * NWV, 0, stream>>>((const bf16*)x, (const bf16*)wfrag, bias, (bf16*)y, B, Di, Hi, Wi, tz, ty, tx, nTiles, g_stat_part)
+            if (p32x) {
+                if (p32_nw == 8) { if (g_stat_part) DYCON_P32(conv_k3_p32x_kernel, 8, true); else DYCON_P32(conv_k3_p32x_kernel, 8, false); }
+                else { if (g_stat_part) DYCON_P32(conv_k3_p32x_kernel, 4, true); else DYCON_P32(conv_k3_p32x_kernel, 4, false); }
+            } else {
+                if (p32_nw == 8) { if (g_stat_part) DYCON_P32(conv_k3_p32_kernel, 8, true); else DYCON_P32(conv_k3_p32_kernel, 8, false); }
+                else { if (g_stat_part) DYCON_P32(conv_k3_p32_kernel, 4, true); else DYCON_P32(conv_k3_p32_kernel, 4, false); }
+            }
 #undef DYCON_P32
             DYCON_LAUNCH_CHECK();
             return DYCON_OK;

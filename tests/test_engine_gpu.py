@@ -26,12 +26,17 @@ def _stats(t):
 
 
 def within_budget(hip, ref32, ref64, what, floor=1e-4):
-    """|hip - ref64| <= the north-star's 1e-4 (abs + rel), AND <= 2 |ref32 - ref64| + 1e-6 in the max norm -- or, where the
-    reference's own fp32 run is further than `floor` from its fp64 twin, at least within that measured budget."""
+    """|hip - ref64| <= 2 |ref32 - ref64| + 1e-6 in the max norm (twice the reference's OWN fp32 error against its fp64 twin), AND
+    element-wise within the north-star's 1e-4 (abs + rel) of the fp64 twin -- or, where the reference's own fp32 run is itself further
+    than `floor` from that twin (the second step of a 2-step trace sits behind an optimiser update and a handful of ReLU decisions
+    at round-off distance from zero: the fp32 and fp64 runs of the REFERENCE then follow two trajectories ~3e-4 apart), within 1e-4
+    of ONE of the reference's two trajectories: a value may not sit between or beside them."""
     hip, ref32, ref64 = (np.asarray(a, dtype=np.float64) for a in (hip, ref32, ref64))
     e_hip, e_ref = np.abs(hip - ref64).max(), np.abs(ref32 - ref64).max()
-    print(f"{what}: |hip-ref64| {e_hip:.3e}, reference's own |ref32-ref64| {e_ref:.3e}")
+    print(f"{what}: |hip-ref64| {e_hip:.3e}, |hip-ref32| {np.abs(hip - ref32).max():.3e}, reference's own |ref32-ref64| {e_ref:.3e}")
     assert e_hip <= 2 * e_ref + 1e-6, f"{what}: HIP error {e_hip:.3e} exceeds twice the reference's own fp32 error {e_ref:.3e}"
+    if e_ref > floor and np.allclose(hip, ref32, rtol=floor, atol=floor):
+        return          # on the reference's fp32 trajectory
     np.testing.assert_allclose(hip, ref64, rtol=floor, atol=floor, err_msg=what)
 
 
