@@ -50,6 +50,7 @@ SIGNATURES = {
     "dycon_conv_stats_chunks": (I, [I, I, I, I, I, I, I, I]),
     "dycon_conv_gemm_stats": (I, [P, P, P, P, I, I, I, I, I, I, I, P, Z, P]),
     "dycon_norm_fwd_parts": (I, [P, P, I, I, L, I, I, F, P, P, P, I, P, P, P, P, F, P, I, P]),
+    "dycon_norm_stats_parts": (I, [I, I, L, I, I, F, P, P, P, F, P, I, P]),
     "dycon_norm_bwd_ab_offset": (Z, [I, L, I]),
     "dycon_norm_bwd_stats": (I, [P, P, I, I, L, I, I, P, P, P, I, P, P, P, P, Z, P]),
     "dycon_first_block_bwd_workspace": (Z, [I, I, I, I]),

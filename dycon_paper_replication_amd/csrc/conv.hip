@@ -669,6 +669,47 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? CL_LB2 : 1) void conv_k3_lds_ker
 //   * each XCD owns one contiguous range of tiles: the 2.3x halo overlap between neighbouring tiles is served by that XCD's L2.
 // LDS A-fragment reads (one ds_read_b128 per MFMA, the array's limit) and the HBM stream are then the two bounds.
 // ------------------------------------------------------------------------------------------------
+// Statistics epilogue of the persistent 96^3 kernels (conv_k3_p16 / conv_k3_c1 with STATS): per output channel {sum, sum of squares}
+// of the bf16 values the workgroup STORES, accumulated in two registers per lane and n-tile over all tiles of one sample, then
+// reduced over the lane groups and the four waves and written as ONE row [channel][2] per (sample, workgroup) of stat_part
+// ([B][gridDim.x][CB][2] floats) -- the layout dycon_norm_fwd_parts / dycon_norm_stats_parts finalize.  The normalisation that follows
+// then skips its statistics pass over the tensor (at 96^3: 113 MB re-read, ~20 us per site).
+template <int NT>
+struct TileStats {
+    float s1[NT], s2[NT];
+    int b;
+    __device__ __forceinline__ void clear() {
+#pragma unroll
+        for (int j = 0; j < NT; ++j) s1[j] = s2[j] = 0.f;
+    }
+    __device__ __forceinline__ void add(int j, unsigned short bits, bool ok) {
+        const float f = ok ? bf16_bits_to_f32(bits) : 0.f;
+        s1[j] += f;
+        s2[j] += f * f;
+    }
+    // uniform call (all 256 threads): red = NT * 4 waves * 32 floats of LDS
+    __device__ __forceinline__ void flush(float* __restrict__ stat_part, float* red) {
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 15;
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            float a = s1[j], q = s2[j];
+            a += __shfl_xor(a, 16, 64); q += __shfl_xor(q, 16, 64);
+            a += __shfl_xor(a, 32, 64); q += __shfl_xor(q, 32, 64);
+            if (lane < 16) { red[(wave * NT * 16 + j * 16 + r) * 2] = a; red[(wave * NT * 16 + j * 16 + r) * 2 + 1] = q; }
+        }
+        __syncthreads();
+        if ((int)threadIdx.x < NT * 32) {
+            float v = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) v += red[w * NT * 32 + threadIdx.x];
+            stat_part[((long long)b * gridDim.x + blockIdx.x) * (NT * 32) + threadIdx.x] = v;
+        }
+        __syncthreads();
+        clear();
+    }
+};
+
 constexpr int P16_RP = 16;                                  // x-row pitch of the halo image in voxels (conflict-free, see above)
 constexpr int P16_XH = CL_HZ * CL_HY * P16_RP * 16;         // halo image, bf16 elements (30 KB)
 #ifndef P16_WGS
@@ -704,17 +745,24 @@ struct TileGeo {            // wave-uniform (SGPR) description of one tile
     int inner;              // the whole 6x10x10 halo lies inside the volume: no clamping, no zero padding
 };
 
-template <int DEPTH, bool ACC>
+template <int DEPTH, bool ACC, bool STATS = false>
 __global__ __launch_bounds__(256, P16_WGS) void conv_k3_p16_kernel(const bf16* __restrict__ X, const bf16* __restrict__ Wf,
                                                                    const float* __restrict__ bias, bf16* __restrict__ Y, int B,
                                                                    int D, int H, int W, int tilesZ, int tilesY, int tilesX,
-                                                                   int nTiles) {
+                                                                   int nTiles, float* __restrict__ stat_part = nullptr) {
     constexpr int OS = 16 + 8;                               // output staging row stride (elements): +16 B against conflicts
     __shared__ __attribute__((aligned(16))) unsigned short Xh[P16_XH];
     __shared__ __attribute__((aligned(16))) unsigned short Ot[CL_NV * OS];
+    __shared__ float sred[STATS ? 4 * 32 : 1];
     int tile, t_end, t_stride;
     xcd_tile_range(nTiles, tile, t_end, t_stride);
+    if (STATS && threadIdx.x < 32)                           // rows of the samples this workgroup never touches: zero
+        for (int n = 0; n < B; ++n) stat_part[((long long)n * gridDim.x + blockIdx.x) * 32 + threadIdx.x] = 0.f;
     if (tile >= t_end) return;                               // (uniform) nothing to do: keeps every wait below on a single path
+    TileStats<1> ts;
+    ts.clear();
+    ts.b = -1;
+    const int tiles_per_sample = tilesZ * tilesY * tilesX;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 15, kg = lane >> 4;
     bf16x8 bfr[14];                                          // K = 27 taps x 16 channels = 14 k-steps of 32 (tap 27 = zero padding)
@@ -821,13 +869,24 @@ __global__ __launch_bounds__(256, P16_WGS) void conv_k3_p16_kernel(const bf16* _
             for (int m = 0; m < 4; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[m], bfr[ks], acc[m], 0, 0, 0);
         }
         __syncthreads();                                     // halo image consumed; previous tile's Ot fully stored
+        const bool full = gcur.z0 + CL_TZ <= D && gcur.y0 + CL_TY <= H && gcur.x0 + CL_TX <= W;
+        if (STATS && cur < t_end) {                          // (uniform) a new sample begins: publish the finished one's sums
+            const int bs = cur / tiles_per_sample;
+            if (bs != ts.b) { if (ts.b >= 0) ts.flush(stat_part, sred); ts.b = bs; }
+        }
 #pragma unroll
         for (int m = 0; m < 4; ++m)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) Ot[((wave * 4 + m) * 16 + 4 * kg + i) * OS + r] = f32_to_bf16_bits(acc[m][i] + bv);
+            for (int i = 0; i < 4; ++i) {
+                const unsigned short bits = f32_to_bf16_bits(acc[m][i] + bv);
+                Ot[((wave * 4 + m) * 16 + 4 * kg + i) * OS + r] = bits;
+                if (STATS) {                                 // voxel (z = wave, y = 2 m + (4 kg + i) / 8, x = (4 kg + i) % 8) of the tile
+                    const int vy = 2 * m + ((4 * kg + i) >> 3), vx = (4 * kg + i) & 7;
+                    ts.add(0, bits, cur < t_end && (full || (gcur.z0 + wave < D && gcur.y0 + vy < H && gcur.x0 + vx < W)));
+                }
+            }
         store_halo(gst, st);
         __syncthreads();
-        const bool full = gcur.z0 + CL_TZ <= D && gcur.y0 + CL_TY <= H && gcur.x0 + CL_TX <= W;
         bf16* ybase = Y + gcur.org;
         if (cur < t_end) {                                   // (else: idle slot of the unrolled tail -- a clamped tile, nothing stored)
 #pragma unroll
@@ -876,6 +935,7 @@ __global__ __launch_bounds__(256, P16_WGS) void conv_k3_p16_kernel(const bf16* _
             one_tile(tile + 2 * t_stride, gcur, g2, s2, g0, s0);
         }
     }
+    if (STATS && ts.b >= 0) ts.flush(stat_part, sred);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1464,14 +1524,21 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_k3_p32x_kernel(const bf16* __
 // First layer (ONE input channel -> 16 * NT): K = 27 taps, padded to a single 32-wide k-step whose A fragment is gathered
 // from a 1.2 KB scalar halo image (8 ds_read_u16 per lane and m-tile).  One MFMA per 16 voxels and n-tile: the kernel is a
 // pure HBM stream of its output (2 B in, 32 * NT B out per voxel).  wfrag = dycon_pack_bfrag(T = 27, Cin = 1).
-template <int NT>
+template <int NT, bool STATS = false>
 __global__ __launch_bounds__(256) void conv_k3_c1_kernel(const bf16* __restrict__ X, const bf16* __restrict__ Wf,
                                                          const float* __restrict__ bias, bf16* __restrict__ Y, int B, int D, int H,
-                                                         int W, int tilesZ, int tilesY, int tilesX, int nTiles, int accumulate) {
+                                                         int W, int tilesZ, int tilesY, int tilesX, int nTiles, int accumulate,
+                                                         float* __restrict__ stat_part = nullptr) {
     constexpr int XP = 12;                                   // x-row pitch of the scalar image (elements)
     constexpr int CB = NT * 16, OS = CB + 8;
     __shared__ unsigned short Xs[CL_HZ * CL_HY * XP];
     __shared__ __attribute__((aligned(16))) unsigned short Ot[CL_NV * OS];
+    __shared__ float sred[STATS ? 4 * NT * 32 : 1];
+    if (STATS && (int)threadIdx.x < NT * 32)                 // rows of the samples this workgroup never touches: zero
+        for (int n = 0; n < B; ++n) stat_part[((long long)n * gridDim.x + blockIdx.x) * (NT * 32) + threadIdx.x] = 0.f;
+    TileStats<NT> ts;
+    ts.clear();
+    ts.b = -1;
     const unsigned short* Xg = reinterpret_cast<const unsigned short*>(X);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 15, kg = lane >> 4;
@@ -1544,17 +1611,25 @@ __global__ __launch_bounds__(256) void conv_k3_c1_kernel(const bf16* __restrict_
                 acc[m][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr, bfr[j], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
         }
         __syncthreads();
+        int b, z0, y0, x0;
+        tile_origin(tile, b, z0, y0, x0);
+        if (STATS && b != ts.b) { if (ts.b >= 0) ts.flush(stat_part, sred); ts.b = b; }      // (uniform)
+        const bool full = z0 + CL_TZ <= D && y0 + CL_TY <= H && x0 + CL_TX <= W;
 #pragma unroll
         for (int m = 0; m < 4; ++m)
 #pragma unroll
             for (int j = 0; j < NT; ++j)
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    Ot[((wave * 4 + m) * 16 + 4 * kg + i) * OS + j * 16 + r] = f32_to_bf16_bits(acc[m][j][i] + bv[j]);
+                for (int i = 0; i < 4; ++i) {
+                    const unsigned short bits = f32_to_bf16_bits(acc[m][j][i] + bv[j]);
+                    Ot[((wave * 4 + m) * 16 + 4 * kg + i) * OS + j * 16 + r] = bits;
+                    if (STATS) {
+                        const int vy = 2 * m + ((4 * kg + i) >> 3), vx = (4 * kg + i) & 7;
+                        ts.add(j, bits, full || (z0 + wave < D && y0 + vy < H && x0 + vx < W));
+                    }
+                }
         if (has_next) store_halo();
         __syncthreads();
-        int b, z0, y0, x0;
-        tile_origin(tile, b, z0, y0, x0);
         constexpr int PPR = CB / 8;
 #pragma unroll
         for (int it = 0; it < PPR; ++it) {
@@ -1573,6 +1648,7 @@ __global__ __launch_bounds__(256) void conv_k3_c1_kernel(const bf16* __restrict_
             st16(yp, o);
         }
     }
+    if (STATS && ts.b >= 0) ts.flush(stat_part, sred);
 }
 
 // y[m, n] (+)= bias[n] + sum_z slab[z][m][n]   (ordered: deterministic)
@@ -3049,8 +3125,11 @@ static bool conv_p32_shape(int dtype, int mode, int scatter, int accumulate, int
 }
 // rows per sample of the statistics partials a dycon_conv_gemm_stats call of this shape writes (0: shape not served)
 extern "C" int dycon_conv_stats_chunks(int dtype, int mode, int B, int Di, int Hi, int Wi, int Cin, int Cout) {
-    if (!conv_p32_shape(dtype, mode, 0, 0, B, Di, Hi, Wi, Cin, Cout)) return 0;
     const int nTiles = B * cdiv(Di, CL_TZ) * cdiv(Hi, CL_TY) * cdiv(Wi, CL_TX);
+    // the persistent kernels of the 16-channel level (conv_k3_p16 16 -> 16, conv_k3_c1 1 -> 16): one row per workgroup of their grids
+    if (dtype == DYCON_BF16 && mode == DYCON_CONV_K3 && Cout == 16 && (Cin == 16 || Cin == 1) && (long long)Di * Hi * Wi >= 13824)
+        return 8 * min(cdiv(nTiles, 8), Cin == 16 ? 32 * P16_WGS : 128);
+    if (!conv_p32_shape(dtype, mode, 0, 0, B, Di, Hi, Wi, Cin, Cout)) return 0;
     return 8 * min(cdiv(nTiles, 8), 32);
 }
 extern "C" int dycon_conv_gemm_ex(const void* x, const void* wfrag, const float* bias, void* y, int dtype, int mode,
@@ -3101,7 +3180,9 @@ extern "C" int dycon_conv_gemm_ex(const void* x, const void* wfrag, const float*
             const bf16 *xp = (const bf16*)x, *wp = (const bf16*)wfrag;
             bf16* yp = (bf16*)y;
             if (Cin == 16 && accumulate) conv_k3_p16_kernel<P16_DEPTH, true><<<8 * per_xcd, 256, 0, stream>>>(xp, wp, bias, yp, B, Di, Hi, Wi, tz, ty, tx, nTiles);
+            else if (Cin == 16 && g_stat_part) conv_k3_p16_kernel<P16_DEPTH, false, true><<<8 * per_xcd, 256, 0, stream>>>(xp, wp, bias, yp, B, Di, Hi, Wi, tz, ty, tx, nTiles, g_stat_part);
             else if (Cin == 16) conv_k3_p16_kernel<P16_DEPTH, false><<<8 * per_xcd, 256, 0, stream>>>(xp, wp, bias, yp, B, Di, Hi, Wi, tz, ty, tx, nTiles);
+            else if (Cout == 16 && g_stat_part && !accumulate) conv_k3_c1_kernel<1, true><<<8 * per_xcd, 256, 0, stream>>>(xp, wp, bias, yp, B, Di, Hi, Wi, tz, ty, tx, nTiles, 0, g_stat_part);
             else if (Cout == 16) conv_k3_c1_kernel<1><<<8 * per_xcd, 256, 0, stream>>>(xp, wp, bias, yp, B, Di, Hi, Wi, tz, ty, tx, nTiles, accumulate);
             else if (Cout == 32) conv_k3_c1_kernel<2><<<8 * per_xcd, 256, 0, stream>>>(xp, wp, bias, yp, B, Di, Hi, Wi, tz, ty, tx, nTiles, accumulate);
             else conv_k3_c1_kernel<4><<<8 * per_xcd, 256, 0, stream>>>(xp, wp, bias, yp, B, Di, Hi, Wi, tz, ty, tx, nTiles, accumulate);
@@ -3113,7 +3194,11 @@ extern "C" int dycon_conv_gemm_ex(const void* x, const void* wfrag, const float*
         if (p32_on && Cin == 32 && Cout == 32 && !accumulate && nTiles >= 1024) {
             const int per_xcd = min(cdiv(nTiles, 8), 32);
             static const long long p32_nw = env_ll("DYCON_P32_WAVES", 8);
-            static const bool p32x = env_ll("DYCON_P32X", 1) != 0;     // 1: the 32x32x16 MFMA form (conv_k3_p32x_kernel)
+            // DYCON_P32X=1: the 32x32x16 MFMA form (conv_k3_p32x_kernel).  Measured SLOWER (30.9 vs 28.5 us per launch at 48^3, step
+            // unchanged): equal MFMA cycles per tap, and the chip holds a lower clock on the 32x32 shape (MI355X_MICROARCH.md, DVFS
+            // give-back item 7) -- what the freed issue slots return does not make up for it.  Kept (tested), off.  Read per call:
+            // the tests switch it inside one process.
+            const bool p32x = env_ll("DYCON_P32X", 0) != 0;
 #define DYCON_P32(KRN, NWV, STV) KRN<NWV, STV><<<8 * per_xcd, 64 * NWV, 0, stream>>>((const bf16*)x, (const bf16*)wfrag, bias, (bf16*)y, B, Di, Hi, Wi, tz, ty, tx, nTiles, g_stat_part)
             if (p32x) {
                 if (p32_nw == 8) { if (g_stat_part) DYCON_P32(conv_k3_p32x_kernel, 8, true); else DYCON_P32(conv_k3_p32x_kernel, 8, false); }

@@ -752,6 +752,17 @@ extern "C" int dycon_norm_fwd_parts(const void* x, void* y, int dtype, int Nb, l
     return dycon_norm_apply(x, y, dtype, Nb, V, C, G, stats, gamma, beta, relu, skip, chan_scale, stream);
 }
 
+// the finalize launch alone: mean / rstd per (n, g) from a producer's partials (for consumers that apply the statistics themselves:
+// dycon_norm_head_fwd, the first block's backward)
+extern "C" int dycon_norm_stats_parts(int dtype, int Nb, long long V, int C, int G, float eps, float* stats, float* running_mean,
+                                      float* running_var, float momentum, const float* part, int chunks, dycon_stream_t stream) {
+    DYCON_REQUIRE(stats && part && chunks > 0, "norm_stats_parts: bad arguments");
+    if (int e = norm_check("norm_stats_parts", dtype, Nb, V, C, G)) return e;
+    norm_finalize_stats_kernel<<<Nb * G, 256, 0, stream>>>(part, Nb, chunks, C, G, V, eps, stats, running_mean, running_var, momentum);
+    DYCON_LAUNCH_CHECK();
+    return DYCON_OK;
+}
+
 extern "C" int dycon_norm_bwd(const void* src, int from_y, const void* gy, void* gx, int dtype, int Nb, long long V, int C,
                               int G, const float* stats, const float* gamma, const float* beta, int relu,
                               const float* chan_scale, float* dgamma, float* dbeta, float* workspace, size_t ws_bytes,

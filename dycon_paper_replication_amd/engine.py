@@ -201,6 +201,7 @@ class Engine:
         self.fuse_head = True            # V-Net: the 2-class head inside the last normalisation's passes (_norm_head)
         self.conv_stats = False          # 48^3 level: the persistent convolution takes the statistics of its output (ops.conv_gemm_stats);
                                          # measured neutral for the step (+5 us per convolution against a 7 us statistics launch): off
+        self.conv_stats96 = True         # 96^3 level (conv_k3_c1 / conv_k3_p16): the same -- there the statistics pass re-reads 113 MB
         self._stat_parts = {}
         self.fuse_first = True           # V-Net: block_one's norm backward formed on load by the first layer's weight gradient (_first_block)
         self.one_pass_first = True       # ... as ONE pass (dycon_first_block_bwd) instead of statistics + weight gradient
@@ -345,7 +346,12 @@ class Engine:
                      and x.shape[1] * x.shape[2] * x.shape[3] >= 13824)
         if first_lds:   # first layer on the matrix cores: K = 27 taps in one 32-wide k-step (conv_k3_c1_kernel), see dycon_hip.h
             wf = self._pk((name, "f1"), "frag", w, 27, 1, Cout, Cout, 1, 27, 0, 27)
-            y = ops.conv_gemm(x, wf, b, CONV_K3, Cout, Cout)
+            chunks = ops.conv_stats_chunks(x, Cin, Cout) if (norm_groups and self.conv_stats96 and Cout == 16) else 0
+            if chunks:      # the persistent kernel also takes the statistics of its output (see below)
+                y, part = ops.conv_gemm_stats(x, wf, b, Cout, chunks)
+                self._stat_parts[id(y)] = (part, chunks)
+            else:
+                y = ops.conv_gemm(x, wf, b, CONV_K3, Cout, Cout)
         elif skinny:
             assert kind in ("k3", "1x1"), "skinny path only for the first conv and the 1x1 heads"
             wt = self._pk((name, "tcn"), "tcn", w, T, Cin, Cout, Cout, 1, T, 0, Cin * T)
@@ -360,8 +366,9 @@ class Engine:
             wf = self._pk((name, "f"), "frag", w, T, Cin, Cout, Cout, 1, T, 0, Cin * T)
             # a GroupNorm / InstanceNorm of the one-launch kind follows (norm_groups > 0): leave a split-K finish to it
             Vo = (x.shape[1] * x.shape[2] * x.shape[3]) // (8 if kind == "k2s2" else 1)
+            want_stats = self.conv_stats96 if (Cin, Cout) == (16, 16) else self.conv_stats       # 96^3 level / 48^3 level
             chunks = (ops.conv_stats_chunks(x, Cin, Cout)
-                      if (norm_groups and self.conv_stats and kind == "k3" and out_dtype == dtype) else 0)
+                      if (norm_groups and want_stats and kind == "k3" and out_dtype == dtype and dtype == torch.bfloat16) else 0)
             if chunks:      # the persistent kernel also takes the statistics of its output: the norm that follows skips its statistics pass
                 y, part = ops.conv_gemm_stats(x, wf, b, Cout, chunks)
                 self._stat_parts[id(y)] = (part, chunks)
@@ -548,7 +555,7 @@ class Engine:
         cname, nname = f"{name}.conv.0", f"{name}.conv.1"
         rec, self.recording = self.recording, False
         try:
-            z = self._conv(cname, x, "k3", need_gx=False)
+            z = self._conv(cname, x, "k3", need_gx=False, norm_groups=(16 if kind == "gn" else (16 if kind == "in" else 0)))
         finally:
             self.recording = rec
         B, C = z.shape[0], z.shape[-1]
@@ -564,7 +571,12 @@ class Engine:
             gamma, beta = self.p[nname + ".weight"], self.p[nname + ".bias"]
             rm, rv = self.buf.get(nname + ".running_mean"), self.buf.get(nname + ".running_var")
         upd = kind == "bn" and training and self.update_bn
-        y, stats = ops.norm_fwd(z, Nb, V, C, G, gamma, beta, True, None, None, 1e-5, rm if upd else None, rv if upd else None, 0.1)
+        if id(z) in self._stat_parts and kind in ("gn", "in"):     # the convolution left the statistics partials behind
+            part, chunks = self._stat_parts.pop(id(z))
+            y, stats = ops.norm_fwd_parts(z, part, chunks, Nb, V, C, G, gamma, beta, True, None, None)
+        else:
+            self._stat_parts.pop(id(z), None)
+            y, stats = ops.norm_fwd(z, Nb, V, C, G, gamma, beta, True, None, None, 1e-5, rm if upd else None, rv if upd else None, 0.1)
         if upd and nname + ".num_batches_tracked" in self.buf:
             nbt = self.buf[nname + ".num_batches_tracked"]
             ops.rec(lambda: nbt.add_(1))
@@ -618,8 +630,13 @@ class Engine:
             rm, rv = self.buf.get(prefix + ".running_mean"), self.buf.get(prefix + ".running_var")
         hw, hb = self.p[head + ".weight"], self.p[head + ".bias"]
         if kind == "bn" and not training:
+            self._stat_parts.pop(id(z), None)
             stats = torch.stack([rm, torch.rsqrt(rv + 1e-5)], 1).reshape(-1).contiguous()
+        elif id(z) in self._stat_parts and kind in ("gn", "in"):   # block_nine's convolution left the statistics partials behind
+            part, chunks = self._stat_parts.pop(id(z))
+            stats = ops.norm_stats_parts(z, part, chunks, Nb, V, C, G)
         else:
+            self._stat_parts.pop(id(z), None)
             upd = kind == "bn" and training and self.update_bn
             stats = ops.norm_stats(z, Nb, V, C, G, 1e-5, rm if upd else None, rv if upd else None, 0.1)
             if upd and prefix + ".num_batches_tracked" in self.buf:

@@ -334,7 +334,8 @@ def conv_gemm_stats(x, wfrag, bias, Cout, chunks):
     B, D, H, W, Cin = x.shape
     y = torch.empty((B, D, H, W, Cout), dtype=x.dtype, device=x.device)
     part = torch.empty(B * chunks * Cout * 2, dtype=torch.float32, device=x.device)
-    with _Region("conv_k3_lds", (x.numel() + y.numel()) * _es(x) + 27 * Cin * Cout * _es(x), 2 * (y.numel() // Cout) * 27 * Cin * Cout):
+    rname = "conv_k3_p16" if (Cin, Cout) == (16, 16) else ("conv_k3_c1" if Cin == 1 else "conv_k3_lds")
+    with _Region(rname, (x.numel() + y.numel()) * _es(x) + 27 * Cin * Cout * _es(x), 2 * (y.numel() // Cout) * 27 * Cin * Cout):
         call("dycon_conv_gemm_stats", _p(x), _p(wfrag), _p(bias), _p(y), dt(x), B, D, H, W, Cin, Cout, _p(part), part.numel() * 4, _s())
     return y, part
 
@@ -425,6 +426,14 @@ def norm_fwd_parts(x, part, chunks, Nb, V, C, G, gamma=None, beta=None, relu=Tru
         call("dycon_norm_fwd_parts", _p(x), _p(y), dt(x), Nb, V, C, G, eps, _p(stats), _p(gamma), _p(beta), int(relu), _p(skip),
              _p(chan_scale), _p(running_mean), _p(running_var), momentum, _p(part), chunks, _s())
     return y, stats
+
+
+def norm_stats_parts(x, part, chunks, Nb, V, C, G, eps=1e-5, running_mean=None, running_var=None, momentum=0.1):
+    """norm_stats without its pass over the tensor: finalize the producing convolution's partials (conv_gemm_stats)"""
+    stats = torch.empty(Nb * G * 2, dtype=torch.float32, device=x.device)
+    with _Region("norm_stats", 0, 0):
+        call("dycon_norm_stats_parts", dt(x), Nb, V, C, G, eps, _p(stats), _p(running_mean), _p(running_var), momentum, _p(part), chunks, _s())
+    return stats
 
 
 def norm_fwd_is_fused(x, V, C, G):

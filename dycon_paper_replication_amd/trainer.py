@@ -70,7 +70,8 @@ class TrainConfig:
     overlap_wgrad: bool = True          # weight-gradient launches of the backward on a second HIP stream (off the dgrad chain)
     overlap_features: bool = True       # feature branch (projection head, embeddings, FeCL forward + backward) on its own stream
     split_repack: bool = True           # the student's weight repack off the head of the dependent chain (Engine.repack)
-    conv_stats: bool = False            # norm statistics taken by the producing convolution where it is persistent (measured neutral: off)
+    conv_stats: bool = False            # 48^3 level: norm statistics taken by the persistent convolution (measured neutral: off)
+    conv_stats96: bool = True           # 96^3 level (block_one, block_nine): the same; saves a 113 MB statistics pass per site
     one_pass_first: bool = True         # block_one's backward as one pass over (x, z, gy) (Engine.one_pass_first)
     fuse_first: bool = True             # V-Net: block_one's norm backward inside the first layer's weight gradient (Engine._first_block)
     fuse_head: bool = True              # V-Net: out_conv fused into block_nine's normalisation passes (Engine._norm_head)
@@ -145,6 +146,7 @@ class DyconTrainer:
         self.s_eng.fuse_first = self.t_eng.fuse_first = cfg.fuse_first
         self.s_eng.one_pass_first = self.t_eng.one_pass_first = cfg.one_pass_first
         self.s_eng.conv_stats = self.t_eng.conv_stats = cfg.conv_stats
+        self.s_eng.conv_stats96 = self.t_eng.conv_stats96 = cfg.conv_stats96
         # accumulator form of the norms (engine.use_acc; measured slower, off by default): one arena of zeroed doubles per step,
         # shared by both nets and cleared by ONE launch at the start of the step, before the teacher stream forks
         self.acc_arena = None

@@ -191,6 +191,10 @@ int dycon_norm_head_dparams(const float* workspace, int Nb, long long V, float* 
  * normalisation that follows is then dycon_norm_fwd_parts = finalize + apply, without the pass that re-reads the tensor
  * (BatchNorm: Nb = 1, chunks = B * chunks). */
 int dycon_conv_stats_chunks(int dtype, int mode, int B, int Di, int Hi, int Wi, int Cin, int Cout);
+/* (also served since round 3: the persistent kernels of the 96^3 level, bf16 k=3 16 -> 16 and 1 -> 16.)  dycon_norm_stats_parts is the
+ * finalize alone (stats = mean / rstd per (n, g)), for consumers that apply the statistics themselves (dycon_norm_head_fwd). */
+int dycon_norm_stats_parts(int dtype, int Nb, long long V, int C, int G, float eps, float* stats, float* running_mean,
+                           float* running_var, float momentum, const float* part, int chunks, dycon_stream_t stream);
 int dycon_conv_gemm_stats(const void* x, const void* wfrag, const float* bias, void* y, int dtype, int B, int Di, int Hi,
                           int Wi, int Cin, int Cout, float* stat_part, size_t stat_bytes, dycon_stream_t stream);
 int dycon_norm_fwd_parts(const void* x, void* y, int dtype, int Nb, long long V, int C, int G, float eps, float* stats,

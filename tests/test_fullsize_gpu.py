@@ -241,30 +241,63 @@ def test_step_full_size_vs_oracle(name, patch, okw, tkw):
 
 
 @pytest.mark.parametrize("sp", [(48, 48, 48), (46, 50, 44)])
-@pytest.mark.parametrize("kind", ["gn", "in"])
-def test_conv_takes_norm_statistics(sp, kind):
-    """dycon_conv_gemm_stats + dycon_norm_fwd_parts (the persistent 48^3 convolution adds up {sum, sum of squares} of the values it
-    stores, the normalisation that follows skips its statistics pass) against dycon_conv_gemm + dycon_norm_fwd: same convolution
-    output bit for bit, statistics to fp32 summation order, normalised output within one bf16 step."""
+def test_conv_p32_on_32x32x16_mfma(sp, monkeypatch):
+    """conv_k3_p32x_kernel (DYCON_P32X=1: the persistent 48^3 kernel on v_mfma_f32_32x32x16_bf16 -- measured slower, off by default)
+    against F.conv3d element-wise, against the default kernel within one bf16 step (the k order inside a tap differs), and its
+    statistics epilogue against the default kernel's."""
     from dycon_paper_replication_amd._lib import CONV_K3
-    rng = np.random.default_rng(zlib.crc32(repr((sp, kind)).encode()))
+    rng = np.random.default_rng(sp[1])
     B, C = 4, 32
-    V = sp[0] * sp[1] * sp[2]
     x = torch.from_numpy(rng.standard_normal((B,) + sp + (C,)).astype(np.float32)).to(DEV, BF)
-    w = torch.from_numpy((rng.standard_normal((C, C, 3, 3, 3)) / np.sqrt(27 * C)).astype(np.float32)).to(DEV)
+    w = torch.from_numpy((rng.standard_normal((C, C, 3, 3, 3)) / np.sqrt(27 * C)).astype(np.float32))
+    b = torch.from_numpy(rng.standard_normal(C).astype(np.float32))
+    wf = ops.pack_bfrag(w.to(DEV), BF, 27, C, C, C, 1, 27, 0, C * 27)
+    chunks = ops.conv_stats_chunks(x, C, C)
+    res = {}
+    for v in ("0", "1"):
+        monkeypatch.setenv("DYCON_P32X", v)
+        y = ops.conv_gemm(x, wf, b.to(DEV), CONV_K3, C, C)
+        y2, part = ops.conv_gemm_stats(x, wf, b.to(DEV), C, chunks)
+        torch.cuda.synchronize()
+        assert torch.equal(y, y2)
+        res[v] = (y, part.reshape(B, chunks, C, 2).sum(1))
+    ref = F.conv3d(x.float().cpu().permute(0, 4, 1, 2, 3), w.bfloat16().float(), b, padding=1)
+    assert_bf16_elementwise(nc(res["1"][0]), ref, f"p32x y @ {sp}")
+    assert_bf16_elementwise(nc(res["0"][0]), ref, f"p32 y @ {sp}")
+    d = (res["1"][0].float() - res["0"][0].float()).abs()
+    assert float((d > 2.0 ** -7 * res["0"][0].float().abs() + 1e-3).float().mean()) == 0.0
+    np.testing.assert_allclose(res["1"][1].cpu().numpy(), res["0"][1].cpu().numpy(), rtol=2e-3, atol=0.5)
+
+
+@pytest.mark.parametrize("cin,C,sp", [(32, 32, (48, 48, 48)), (32, 32, (46, 50, 44)), (16, 16, (96, 96, 96)), (16, 16, (50, 44, 46)),
+                                      (1, 16, (96, 96, 96)), (1, 16, (50, 44, 46))])
+@pytest.mark.parametrize("kind", ["gn", "in"])
+def test_conv_takes_norm_statistics(cin, C, sp, kind):
+    """dycon_conv_gemm_stats + dycon_norm_fwd_parts / dycon_norm_stats_parts (the persistent convolutions of the 48^3 and 96^3 levels add
+    up {sum, sum of squares} of the values they store, the normalisation that follows skips its statistics pass) against
+    dycon_conv_gemm + dycon_norm_fwd: same convolution output bit for bit, statistics to fp32 summation order, normalised output
+    within one bf16 step.  Ragged shapes: partial tiles must not count their padding."""
+    from dycon_paper_replication_amd._lib import CONV_K3
+    rng = np.random.default_rng(zlib.crc32(repr((cin, sp, kind)).encode()))
+    B = 4
+    V = sp[0] * sp[1] * sp[2]
+    x = torch.from_numpy(rng.standard_normal((B,) + sp + (cin,)).astype(np.float32)).to(DEV, BF)
+    w = torch.from_numpy((rng.standard_normal((C, cin, 3, 3, 3)) / np.sqrt(27 * cin)).astype(np.float32)).to(DEV)
     b = torch.from_numpy(rng.standard_normal(C).astype(np.float32)).to(DEV)
     gamma = torch.from_numpy(rng.standard_normal(C).astype(np.float32) * 0.5 + 1.0).to(DEV) if kind == "gn" else None
     beta = torch.from_numpy(rng.standard_normal(C).astype(np.float32) * 0.3).to(DEV) if kind == "gn" else None
     G = 16 if kind == "gn" else C
-    wf = ops.pack_bfrag(w, BF, 27, C, C, C, 1, 27, 0, C * 27)
-    chunks = ops.conv_stats_chunks(x, C, C)
+    wf = ops.pack_bfrag(w, BF, 27, cin, C, C, 1, 27, 0, cin * 27)
+    chunks = ops.conv_stats_chunks(x, cin, C)
     assert chunks > 0
     y_ref = ops.conv_gemm(x, wf, b, CONV_K3, C, C)
     n_ref, stats_ref = ops.norm_fwd(y_ref, B, V, C, G, gamma, beta, True)
     y, part = ops.conv_gemm_stats(x, wf, b, C, chunks)
     n, stats = ops.norm_fwd_parts(y, part, chunks, B, V, C, G, gamma, beta, True)
+    stats2 = ops.norm_stats_parts(y, part, chunks, B, V, C, G)
     torch.cuda.synchronize()
     assert torch.equal(y, y_ref)
+    assert torch.equal(stats, stats2)
     np.testing.assert_allclose(stats.cpu().numpy(), stats_ref.cpu().numpy(), rtol=2e-5, atol=2e-6)
     err = float((n.float() - n_ref.float()).abs().max())
     assert err <= 2.0 ** -7 * float(n_ref.float().abs().max()), err

@@ -102,5 +102,46 @@ int main(int argc, char** argv) {
         printf("%-78s %9.2f %9.2f\n", cs.name, gpu / REPS / per, host / REPS / per);
         if (cs.every) for (auto& e : evs) CK(hipEventDestroy(e));
     }
+    // ---- the replayed DyCON step's launch pattern with trivial kernels: 456 launches on 4 streams (226 / 117 / 82 / 31), 55 forks
+    // (event record on the producer + wait on the consumer): what the HIP runtime alone costs the host per step
+    {
+        const int per[4] = {226, 117, 82, 31};
+        std::vector<int> order;
+        int left[4] = {per[0], per[1], per[2], per[3]};
+        for (int i = 0; i < 456; ++i) {                      // proportional interleave
+            int q = 0;
+            double best = -1;
+            for (int k = 0; k < 4; ++k) { const double f = (double)left[k] / per[k]; if (left[k] > 0 && f > best) { best = f; q = k; } }
+            order.push_back(q);
+            --left[q];
+        }
+        for (unsigned flags : {DT, DT | NF}) {
+            std::vector<hipEvent_t> evs(55);
+            for (auto& e : evs) CK(hipEventCreateWithFlags(&e, flags));
+            double gpu = 0, host = 0;
+            for (int r = -2; r < REPS; ++r) {
+                CK(hipDeviceSynchronize());
+                auto h0 = std::chrono::steady_clock::now();
+                CK(hipEventRecord(t0, S[0]));
+                int nf = 0;
+                for (int i = 0; i < 456; ++i) {
+                    const int q = order[i];
+                    hipLaunchKernelGGL(stream_kernel, dim3(256), dim3(256), 0, S[q], (float4*)((char*)a + q * (BIG / 4)),
+                                       (float4*)((char*)b + q * (BIG / 4)), SMALL);
+                    if (i % 8 == 7 && nf < 55) { const int to = 1 + nf % 3; CK(hipEventRecord(evs[nf], S[0])); CK(hipStreamWaitEvent(S[to], evs[nf], 0)); ++nf; }
+                }
+                for (int q = 1; q < 4; ++q) { CK(hipEventRecord(t1, S[q])); CK(hipStreamWaitEvent(S[0], t1, 0)); }
+                CK(hipEventRecord(t1, S[0]));
+                auto h1 = std::chrono::steady_clock::now();
+                CK(hipDeviceSynchronize());
+                float ms;
+                CK(hipEventElapsedTime(&ms, t0, t1));
+                if (r >= 0) { gpu += ms * 1e3; host += std::chrono::duration<double, std::micro>(h1 - h0).count(); }
+            }
+            printf("step pattern: 456 trivial launches on 4 streams + 55 forks (%s): GPU %.0f us, host %.0f us per step\n",
+                   flags == DT ? "torch event flags" : "hipEventDisableSystemFence", gpu / REPS, host / REPS);
+            for (auto& e : evs) CK(hipEventDestroy(e));
+        }
+    }
     return 0;
 }
