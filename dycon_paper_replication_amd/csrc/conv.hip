@@ -290,12 +290,18 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const T* __restrict__ X,
 // ------------------------------------------------------------------------------------------------
 constexpr int CT_BM = 64, CT_BN = 128, CT_AS = 40;          // A rows padded to 80 B: conflict-free ds_read_b128 fragments
 
-__global__ __launch_bounds__(256, 4) void conv_k3_tile_kernel(const bf16* __restrict__ X, const bf16* __restrict__ Wf,
+// KS2 = 32-channel chunks per k-step (1 or 2).  With one chunk per step a wave issues 8 MFMAs (128 matrix cycles) between two barriers
+// and pays, per step, a publish, a request and ~70 scalar instructions of address bookkeeping: PMC (profiles/r03_pmc_small_levels.txt)
+// has 1935 SALU + 1158 VALU instructions per wave against 216 MFMAs, the matrix pipe busy 8.5 % of a wave's life and 42 % of it spent
+// in s_waitcnt / s_barrier.  KS2 = 2 (Cin % 64 == 0: the V-Net's 128- and 256-channel levels) halves the number of steps: 16 MFMAs
+// per barrier, two chunks of the same tap requested with one address computation (LDS 52 KB per workgroup: 3 per CU).
+template <int KS2>
+__global__ __launch_bounds__(256, KS2 == 1 ? 4 : 3) void conv_k3_tile_kernel(const bf16* __restrict__ X, const bf16* __restrict__ Wf,
                                                            const float* __restrict__ bias, bf16* __restrict__ Y,
                                                            float* __restrict__ slab, int B, int D, int H, int W, int Cin, int N,
                                                            int NT, int nKC, int kc_per_split, int accumulate, int span_major = 0) {
-    __shared__ __attribute__((aligned(16))) unsigned short As[2][CT_BM * CT_AS];
-    __shared__ __attribute__((aligned(16))) unsigned short Bs[2][8 * 64 * 8];
+    __shared__ __attribute__((aligned(16))) unsigned short As[2][KS2][CT_BM * CT_AS];
+    __shared__ __attribute__((aligned(16))) unsigned short Bs[2][KS2][8 * 64 * 8];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 15, kg = lane >> 4;
     const int wm = wave >> 1, wn = wave & 1;
@@ -315,7 +321,7 @@ __global__ __launch_bounds__(256, 4) void conv_k3_tile_kernel(const bf16* __rest
     const bool avalid = am < M;
     const int kc0 = slab ? blockIdx.z * kc_per_split : 0;
     const int kc1 = slab ? min(nKC, kc0 + kc_per_split) : nKC;
-    int t = (kc0 * 32) / Cin, c = kc0 * 32 - t * Cin;          // (tap, first channel) of the next k-step to request: Cin % 32 == 0
+    int t = (kc0 * 32) / Cin, c = kc0 * 32 - t * Cin;          // (tap, first channel) of the next k-step to request: Cin % (32 KS2) == 0
     int kreq = kc0;                                            // k-steps are requested strictly in order
     // Address generation is kept OFF the vector ALU (measured: 75 VALU + 50 SALU instructions per k-step against 8 MFMAs when the
     // tap is decoded per thread): a k-step's tap offset and weight-chunk base are wave-uniform (scalar registers), the thread's own
@@ -329,24 +335,31 @@ __global__ __launch_bounds__(256, 4) void conv_k3_tile_kernel(const bf16* __rest
     const unsigned boff = threadIdx.x * 16u;
     // Two register stages keep the global loads of two k-steps in flight under the MFMAs of a third (more stages spill at the
     // register budget that lets several workgroups share a CU, which hides the rest of the L2 latency).
-    struct Stage { uint4 a, b0, b1; };
+    struct Stage { uint4 a[KS2], b0[KS2], b1[KS2]; };
     auto request = [&](Stage& st) {
         const int tt = min(t, 26);
         const int dz = tt / 9, dy = (tt / 3) % 3, dx = tt % 3;                    // wave-uniform
         const char* xs = reinterpret_cast<const char*>(X) + (((long long)((dz - 1) * H + (dy - 1)) * W + (dx - 1)) * Cin + c) * 2;
-        st.a = make_uint4(0, 0, 0, 0);
-        if ((vmask >> tt) & 1u) st.a = *reinterpret_cast<const uint4*>(xs + aoff);
-        const char* ws = reinterpret_cast<const char*>(Wf) + ((long long)min(kreq, nKC - 1) * NT + nt0) * 1024;
-        st.b0 = *reinterpret_cast<const uint4*>(ws + boff);
-        st.b1 = *reinterpret_cast<const uint4*>(ws + boff + 4096);
-        ++kreq;
-        c += 32;
+        const char* ws = reinterpret_cast<const char*>(Wf) + ((long long)min(kreq, nKC - KS2) * NT + nt0) * 1024;
+        const bool in = ((vmask >> tt) & 1u) != 0;
+#pragma unroll
+        for (int u = 0; u < KS2; ++u) {                          // the chunks of a step share the tap: channels c + 32 u
+            st.a[u] = make_uint4(0, 0, 0, 0);
+            if (in && kreq + u < kc1) st.a[u] = *reinterpret_cast<const uint4*>(xs + aoff + 64 * u);
+            st.b0[u] = *reinterpret_cast<const uint4*>(ws + (long long)u * NT * 1024 + boff);
+            st.b1[u] = *reinterpret_cast<const uint4*>(ws + (long long)u * NT * 1024 + boff + 4096);
+        }
+        kreq += KS2;
+        c += 32 * KS2;
         if (c == Cin) { c = 0; ++t; }
     };
     auto publish = [&](const Stage& st, int buf) {
-        *reinterpret_cast<uint4*>(&As[buf][arow * CT_AS + 8 * aq]) = st.a;
-        *reinterpret_cast<uint4*>(&Bs[buf][threadIdx.x * 8]) = st.b0;
-        *reinterpret_cast<uint4*>(&Bs[buf][(threadIdx.x + 256) * 8]) = st.b1;
+#pragma unroll
+        for (int u = 0; u < KS2; ++u) {
+            *reinterpret_cast<uint4*>(&As[buf][u][arow * CT_AS + 8 * aq]) = st.a[u];
+            *reinterpret_cast<uint4*>(&Bs[buf][u][threadIdx.x * 8]) = st.b0[u];
+            *reinterpret_cast<uint4*>(&Bs[buf][u][(threadIdx.x + 256) * 8]) = st.b1[u];
+        }
     };
     f32x4 acc[2][4];
 #pragma unroll
@@ -354,17 +367,20 @@ __global__ __launch_bounds__(256, 4) void conv_k3_tile_kernel(const bf16* __rest
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[m][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     auto compute = [&](int buf) {
-        bf16x8 a[2], b[4];
 #pragma unroll
-        for (int m = 0; m < 2; ++m)
-            a[m] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(&As[buf][(wm * 32 + m * 16 + r) * CT_AS + 8 * kg]));
+        for (int u = 0; u < KS2; ++u) {
+            bf16x8 a[2], b[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-            b[j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(&Bs[buf][((wn * 4 + j) * 64 + lane) * 8]));
+            for (int m = 0; m < 2; ++m)
+                a[m] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(&As[buf][u][(wm * 32 + m * 16 + r) * CT_AS + 8 * kg]));
 #pragma unroll
-        for (int m = 0; m < 2; ++m)
+            for (int j = 0; j < 4; ++j)
+                b[j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(&Bs[buf][u][((wn * 4 + j) * 64 + lane) * 8]));
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[m][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[m], b[j], acc[m][j], 0, 0, 0);
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[m][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[m], b[j], acc[m][j], 0, 0, 0);
+        }
     };
 
     Stage s0, s1;
@@ -372,7 +388,7 @@ __global__ __launch_bounds__(256, 4) void conv_k3_tile_kernel(const bf16* __rest
     publish(s0, 0);                                            // k-step 0
     request(s1); request(s0);                                  // k-steps 1, 2 in flight (stage of k-step j: j % 2)
     __syncthreads();
-    const int nk = kc1 - kc0;
+    const int nk = (kc1 - kc0 + KS2 - 1) / KS2;
     // iteration j: MFMAs on LDS buffer j % 2; publish k-step j + 1 into the other buffer; request k-step j + 3 into the freed stage
     for (int j = 0; j < nk; j += 2) {
         compute(0); publish(s1, 1); request(s1); __syncthreads();
@@ -3051,6 +3067,7 @@ static SplitK conv_tile_plan(long long M, int N, int Cin) {
     if (s > nKC / 8) s = nKC / 8;                             // at least 8 k-steps per split
     if (s < 2) return p;
     p.kc_per_split = (int)((nKC + s - 1) / s);
+    if (Cin % 64 == 0) p.kc_per_split = (p.kc_per_split + 1) & ~1;    // whole 64-channel k-steps (conv_k3_tile_kernel<2>)
     p.splits = (nKC + p.kc_per_split - 1) / p.kc_per_split;
     return p;
 }
@@ -3233,8 +3250,13 @@ extern "C" int dycon_conv_gemm_ex(const void* x, const void* wfrag, const float*
         SplitK sk = conv_tile_plan(M, N, Cin);
         const bool split = sk.splits > 1 && workspace && ws_bytes >= (size_t)sk.splits * M * N * sizeof(float);
         dim3 grid(cdiv(M, CT_BM), N / CT_BN, split ? sk.splits : 1);
-        conv_k3_tile_kernel<<<grid, 256, 0, stream>>>((const bf16*)x, (const bf16*)wfrag, bias, (bf16*)y, split ? workspace : nullptr, B,
-                                                      Di, Hi, Wi, Cin, N, NT, nKC, sk.kc_per_split, accumulate, split && defer_finish);
+        static const bool tile64 = env_ll("DYCON_TILE_KS64", 1) != 0;
+        if (tile64 && Cin % 64 == 0 && sk.kc_per_split % 2 == 0)
+            conv_k3_tile_kernel<2><<<grid, 256, 0, stream>>>((const bf16*)x, (const bf16*)wfrag, bias, (bf16*)y, split ? workspace : nullptr, B,
+                                                             Di, Hi, Wi, Cin, N, NT, nKC, sk.kc_per_split, accumulate, split && defer_finish);
+        else
+            conv_k3_tile_kernel<1><<<grid, 256, 0, stream>>>((const bf16*)x, (const bf16*)wfrag, bias, (bf16*)y, split ? workspace : nullptr, B,
+                                                             Di, Hi, Wi, Cin, N, NT, nKC, sk.kc_per_split, accumulate, split && defer_finish);
         DYCON_LAUNCH_CHECK();
         if (split && !defer_finish) {
             long long blocks = (M * N / 4 + 255) / 256;
