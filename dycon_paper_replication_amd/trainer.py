@@ -175,6 +175,14 @@ class DyconTrainer:
         # The feature branch -- projection head -> normalised embeddings -> FeCL, forward and backward -- meets the segmentation
         # branch only at the bottleneck tensor and in the scalar loss: it runs on a third stream, beside the decoder.
         self.feat = torch.cuda.Stream(device=self.device) if cfg.overlap_features else None
+        # HIP multiplexes a process's streams onto 4 hardware queues.  The data-parallel run adds torch's collective stream: with
+        # five or more busy streams two of them SHARE a queue and serialise (profiles/r03_ddp_one_rank_trace.txt: the teacher forward and
+        # the weight-gradient launches, +0.28 ms/step), and raising GPU_MAX_HW_QUEUES to 8 oversubscribes the queues (7.4 ms/step).
+        # So a data-parallel rank runs the feature branch on the teacher's stream -- it needs the teacher's features anyway and that
+        # stream is idle from the end of the teacher forward on -- and issues its collectives from the weight-gradient stream:
+        # main, teacher + features, weight gradients, RCCL = four.
+        if self.ddp and self.feat is not None and cfg.overlap_teacher:
+            self.feat = self.side
         self.s_eng.feat_stream = self.feat
         self.marks = None            # see _mark
         self._rp = None              # recorded step: dict(sig, rec, by_name, it, out, vol, lab)
@@ -196,7 +204,6 @@ class DyconTrainer:
             self.buckets = [(by_off[lo], lo, hi) for lo, hi in zip(cuts[:-1], cuts[1:])]
             self._bucket_of = {name: (lo, hi) for name, lo, hi in self.buckets}
             self._pending = []
-            self.comm = torch.cuda.Stream(device=self.device)
             self.s_eng.on_param_grads = self._on_param_grads
 
     def _mark(self, tag, stream=None):
@@ -213,19 +220,18 @@ class DyconTrainer:
         if rng is not None:
             # The bucket holds gradients written on up to three streams: conv weights / biases (weight-gradient stream), norm affine
             # parameters (main) and the projection head's parameters (feature stream, whose backward was enqueued first).  The
-            # collective is issued from a FOURTH stream that waits for those three: the data-gradient chain on main never waits for
-            # the weight-gradient stream in mid-backward (it did when the collective was ordered after main: that wait, at four
-            # points of the backward, was most of the 0.3 ms/step the exchange path cost a rank besides wire time).
-            others = [o for o in (self._main, self.feat, self.s_eng.wgrad_stream) if o is not None]
+            # collective is issued from the WEIGHT-GRADIENT stream, which first waits for the other two: that stream trails the chain
+            # it is forked from, so the waits are free, and the data-gradient chain on main never waits for anything in mid-backward.
+            issuer = self.s_eng.wgrad_stream if self.s_eng.wgrad_stream is not None else self._main
+            others = [o for o in (self._main, self.feat, self.s_eng.wgrad_stream) if o is not None and o != issuer]
             evs = [torch.cuda.Event() for _ in others]
             view = self.flat_g[rng[0]:rng[1]]
-            comm = self.comm
 
             def issue():
                 for o, ev in zip(others, evs):
                     ev.record(o)
-                    comm.wait_event(ev)
-                with torch.cuda.stream(comm):         # torch.distributed orders the collective after the current stream
+                    issuer.wait_event(ev)
+                with torch.cuda.stream(issuer):       # torch.distributed orders the collective after the current stream
                     self._pending.append(torch.distributed.all_reduce(view, group=self.pg, async_op=True))
             ops.rec(issue)
 
