@@ -577,6 +577,24 @@ def test_norm_head_fused_equals_norm_then_head(dtype, kind, with_drop):
         close(db, db_ref, 1e-5, 1e-5 * float(db_ref.abs().max()), "dbeta")
     close(gw, gw_ref, 1e-4, 1e-4 * float(gw_ref.abs().max()), "head weight gradient")
     close(gb, gb_ref, 1e-4, 1e-4 * float(gb_ref.abs().max()), "head bias gradient")
+    # bit-reproducibility: the same inputs again, three times, beside a second stream that keeps the memory
+    # system busy with uneven bursts -- every output must repeat bit for bit (ordered two-stage reductions, no float atomics; a
+    # missing barrier between a partial's write and its read-back, or an accumulator cleared late, shows up here as a changed bit)
+    side = torch.cuda.Stream()
+    junk = torch.empty(64 << 20, dtype=torch.uint8, device=DEV)
+    for rep in range(3):
+        with torch.cuda.stream(side):
+            for k in range(1 + 2 * rep):
+                junk[: (8 << 20) * (1 + k % 5)].add_(1)
+        lo2 = ops.norm_head_fwd(x, stats2, Nb, Vn, G, W, hb, gamma, beta, True, cs)
+        dg2, db2 = (torch.empty(C, device=DEV), torch.empty(C, device=DEV)) if affine else (None, None)
+        gx2, pend2 = ops.norm_head_bwd(x, gl, stats2, Nb, Vn, G, W, gamma, beta, True, dg2, db2, cs)
+        gw2, gb2 = torch.empty_like(W), torch.empty_like(hb)
+        ops.norm_head_dparams(pend2, gw2, gb2)
+        torch.cuda.synchronize()
+        assert torch.equal(lo2, logits) and torch.equal(gx2, gx) and torch.equal(gw2, gw) and torch.equal(gb2, gb), f"repetition {rep} differs"
+        if affine:
+            assert torch.equal(dg2, dg) and torch.equal(db2, db), f"repetition {rep}: dgamma / dbeta differ"
 
 
 @pytest.mark.parametrize("kind", ["gn", "in", "bn"])
