@@ -1870,27 +1870,6 @@ __global__ __launch_bounds__(256, 2) void wgrad_k3_bf16_kernel(const bf16* __res
     constexpr int NSX = CIN1 ? (WG_NH + 255) / 256 : (WG_NH * 2 + 255) / 256;
     constexpr int NSG = WG_NV * (CB / 8) / 256 > 0 ? WG_NV * (CB / 8) / 256 : 1;
     uint4 sx[NSX], sg[NSG];
-    // Tile-independent geometry of this thread's staging pieces, computed ONCE (round 3; the per-tile decode of piece -> halo voxel ->
-    // 64-bit address was 431 vector + 184 scalar instructions per tile and wave against 112 MFMAs: the kernel's non-matrix time was
-    // instruction issue, profiles/r03_pmc_small_levels.txt): element offset from the tile's origin voxel, packed halo coordinates for
-    // the bounds test of boundary tiles; interior tiles (the whole halo inside the volume) test nothing.
-    int xrel[NSX], xco[NSX], grel[NSG], gco[NSG];
-#pragma unroll
-    for (int it = 0; it < NSX; ++it) {
-        const int e = threadIdx.x + 256 * it;
-        const int hv = min(CIN1 ? e : e >> 1, WG_NH - 1), half = CIN1 ? 0 : e & 1;
-        const int hx = hv % WG_HX, hy = (hv / WG_HX) % WG_HY, hz = hv / (WG_HX * WG_HY);
-        xrel[it] = CIN1 ? ((hz - 1) * H + (hy - 1)) * W + (hx - 1) : (((hz - 1) * H + (hy - 1)) * W + (hx - 1)) * Cin + ci0 + 8 * half;
-        xco[it] = hz | (hy << 8) | (hx << 16) | (((CIN1 ? e : e >> 1) < WG_NH ? 1 : 0) << 24);
-    }
-#pragma unroll
-    for (int it = 0; it < NSG; ++it) {
-        const int e = threadIdx.x + 256 * it;
-        const int v8 = e % (CB / 8), vv = min(e / (CB / 8), WG_NV - 1);
-        const int vx = vv % WG_TX, vy = (vv / WG_TX) % WG_TY, vz = vv / (WG_TX * WG_TY);
-        grel[it] = ((vz * H + vy) * W + vx) * Cout + co0 + 8 * v8;
-        gco[it] = vz | (vy << 8) | (vx << 16) | ((e < WG_NV * (CB / 8) && co0 + 8 * v8 < Cout ? 1 : 0) << 24);
-    }
     auto load_tile = [&](int tile) {
         int rr = tile;
         const int tx = rr % tilesX; rr /= tilesX;
@@ -1898,30 +1877,27 @@ __global__ __launch_bounds__(256, 2) void wgrad_k3_bf16_kernel(const bf16* __res
         const int tz = rr % tilesZ;
         const int b = rr / tilesZ;
         const int z0 = tz * WG_TZ, y0 = ty * WG_TY, x0 = tx * WG_TX;
-        const long long vorg = (((long long)b * D + z0) * H + y0) * W + x0;                  // origin voxel (wave-uniform)
-        const bool inner = z0 >= 1 && z0 + WG_TZ < D && y0 >= 1 && y0 + WG_TY < H && x0 >= 1 && x0 + WG_TX < W;
-        const unsigned short* xs1 = reinterpret_cast<const unsigned short*>(X) + vorg;
-        const bf16* xs = X + vorg * Cin;
-        const bf16* gs = GY + vorg * Cout;
 #pragma unroll
         for (int it = 0; it < NSX; ++it) {
-            bool ok = (xco[it] >> 24) != 0;
-            if (!inner) {
-                const int z = z0 + (xco[it] & 255) - 1, y = y0 + ((xco[it] >> 8) & 255) - 1, x = x0 + ((xco[it] >> 16) & 255) - 1;
-                ok = ok && (unsigned)z < (unsigned)D && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
-            }
+            const int e = threadIdx.x + 256 * it;
+            const int hv = CIN1 ? e : e >> 1, half = CIN1 ? 0 : e & 1;
+            const int hx = hv % WG_HX, hy = (hv / WG_HX) % WG_HY, hz = hv / (WG_HX * WG_HY);
+            const int z = z0 + hz - 1, y = y0 + hy - 1, x = x0 + hx - 1;
             sx[it] = make_uint4(0, 0, 0, 0);
-            if (ok) {
-                if (CIN1) sx[it].x = xs1[xrel[it]];
-                else sx[it] = *reinterpret_cast<const uint4*>(xs + xrel[it]);
+            if (hv < WG_NH && (unsigned)z < (unsigned)D && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W) {
+                if (CIN1) sx[it].x = reinterpret_cast<const unsigned short*>(X)[(((long long)b * D + z) * H + y) * W + x];
+                else sx[it] = *reinterpret_cast<const uint4*>(X + ((((long long)b * D + z) * H + y) * W + x) * Cin + ci0 + 8 * half);
             }
         }
 #pragma unroll
         for (int it = 0; it < NSG; ++it) {
-            bool ok = (gco[it] >> 24) != 0;
-            if (!inner) ok = ok && z0 + (gco[it] & 255) < D && y0 + ((gco[it] >> 8) & 255) < H && x0 + ((gco[it] >> 16) & 255) < W;
+            const int e = threadIdx.x + 256 * it;
+            const int v8 = e % (CB / 8), vv = e / (CB / 8);
+            const int vx = vv % WG_TX, vy = (vv / WG_TX) % WG_TY, vz = vv / (WG_TX * WG_TY);
+            const int z = z0 + vz, y = y0 + vy, x = x0 + vx;
             sg[it] = make_uint4(0, 0, 0, 0);
-            if (ok) sg[it] = *reinterpret_cast<const uint4*>(gs + grel[it]);
+            if (e < WG_NV * (CB / 8) && z < D && y < H && x < W && co0 + 8 * v8 < Cout)
+                sg[it] = *reinterpret_cast<const uint4*>(GY + ((((long long)b * D + z) * H + y) * W + x) * Cout + co0 + 8 * v8);
         }
     };
     auto store_tile = [&]() {
