@@ -26,6 +26,12 @@ __global__ void stream_kernel(const float4* __restrict__ in, float4* __restrict_
     }
 }
 
+__global__ void spin_kernel(long long ticks, float* out) {          // keeps the stream busy while the host pre-queues a chain
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) {}
+    if (out && threadIdx.x == 0) out[0] = 1.f;
+}
+
 struct Case { const char* name; long n16; int every; unsigned flags; bool other_kernel; int streams; };
 
 int main(int argc, char** argv) {
@@ -101,6 +107,25 @@ int main(int argc, char** argv) {
         const int per = cs.streams == 1 ? N : N / 4;
         printf("%-78s %9.2f %9.2f\n", cs.name, gpu / REPS / per, host / REPS / per);
         if (cs.every) for (auto& e : evs) CK(hipEventDestroy(e));
+    }
+    // ---- the same chains PRE-QUEUED behind a 4 ms blocker kernel (100 MHz wall clock): the host has enqueued everything before the
+    // first chain kernel may start, so the figure is the GPU's own cost per dependent launch, not the host's enqueue rate
+    for (int big = 0; big < 2; ++big) {
+        double gpu = 0;
+        for (int r = -1; r < 5; ++r) {
+            CK(hipDeviceSynchronize());
+            hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, A, 400000ll, (float*)c);
+            CK(hipEventRecord(t0, A));
+            for (int i = 0; i < N; ++i)
+                hipLaunchKernelGGL(stream_kernel, dim3(big ? 2048 : 256), dim3(256), 0, A, (i & 1) ? b : a, (i & 1) ? a : b, big ? LARGE : SMALL);
+            CK(hipEventRecord(t1, A));
+            CK(hipDeviceSynchronize());
+            float ms;
+            CK(hipEventElapsedTime(&ms, t0, t1));
+            if (r >= 0) gpu += ms * 1e3;
+        }
+        printf("%-78s %9.2f %9s\n", big ? "streaming 28 MB kernels, one stream, PRE-QUEUED behind a blocker" : "trivial kernels, one stream, PRE-QUEUED behind a blocker",
+               gpu / 5 / N, "-");
     }
     // ---- the replayed DyCON step's launch pattern with trivial kernels: 456 launches on 4 streams (226 / 117 / 82 / 31), 55 forks
     // (event record on the producer + wait on the consumer): what the HIP runtime alone costs the host per step
