@@ -1,9 +1,9 @@
 #!/bin/bash
-# Everything the round's measured claims rest on, in one pass on the GPU box (tools/measure_round.sh <tag>, e.g. r02):
+# Everything the round's measured claims rest on, in one pass on the GPU box (tools/measure_round.sh <tag>, e.g. r03):
 #   gpurun_out/<tag>/bench_line.json      the default bench run (what the driver runs)
 #   gpurun_out/<tag>/prof/*               rocprofv3 --kernel-trace --stats of a short bench run
 #   gpurun_out/pmc_<tag>_{fetch,write}/   the two HBM-traffic counter passes
-tag=${1:-r02}
+tag=${1:-r03}
 R=$GRAFT_REPO_ROOT
 mkdir -p $R/gpurun_out/$tag
 cd $R && python bench.py > gpurun_out/$tag/bench_line.json 2> gpurun_out/$tag/bench_line.err || exit 1
