@@ -411,7 +411,7 @@ __global__ __launch_bounds__(256) void norm_fused_fwd_kernel(T* __restrict__ X, 
     constexpr int VN = Vec16<T>::N, NVEC = SPAN / VN;
     __shared__ float sm[4 * 2 * SPAN];
     constexpr int cpg = CPG;
-    const int n = blockIdx.y, c0 = blockIdx.x * SPAN;
+    const int n = blockIdx.x, c0 = blockIdx.y * SPAN;      // sample fastest: the spans of one sample share XCDs (see the launch)
     T* xp = X + (long long)n * V * C + c0;
     float acc[2 * SPAN];
 #pragma unroll
@@ -483,7 +483,7 @@ __global__ __launch_bounds__(256) void norm_fused_fwd_kernel(T* __restrict__ X, 
             const int g = c / cpg;
             stats[((long long)n * G + g) * 2] = (float)mean;
             stats[((long long)n * G + g) * 2 + 1] = rstd;
-            if (running_mean && gridDim.y == 1 && G == C) {
+            if (running_mean && gridDim.x == 1 && G == C) {
                 running_mean[g] = (1.f - momentum) * running_mean[g] + momentum * (float)mean;
                 const double unb = cnt > 1.0 ? var * cnt / (cnt - 1.0) : var;
                 running_var[g] = (1.f - momentum) * running_var[g] + momentum * (float)unb;
@@ -531,7 +531,7 @@ __global__ __launch_bounds__(256) void norm_fused_bwd_kernel(const T* __restrict
     constexpr int VN = Vec16<T>::N, NVEC = SPAN / VN;
     __shared__ float sm[4 * 2 * SPAN];
     constexpr int cpg = CPG;
-    const int n = blockIdx.y, c0 = blockIdx.x * SPAN;
+    const int n = blockIdx.x, c0 = blockIdx.y * SPAN;      // sample fastest: the spans of one sample share XCDs (see the launch)
     const T* xp = X + (long long)n * V * C + c0;
     const T* gp = GY + (long long)n * V * C + c0;
     float mean[SPAN], rstd[SPAN], gm[SPAN], bt[SPAN], cs[SPAN];
@@ -659,7 +659,9 @@ extern "C" int dycon_norm_fwd_slab(const float* slab, int splits, const float* c
     DYCON_REQUIRE(norm_fused_ok(dtype, V, C, G), "norm_fwd_slab: this shape is not served by the one-launch norm (ask dycon_norm_fwd_is_fused)");
     const int cpg = C / G, span = cpg > 8 ? cpg : 8;
     const long long MN = (long long)Nb * V * C;
-    dim3 grid(C / span, Nb);
+    dim3 grid(Nb, C / span);      // x = sample: workgroups are dealt to the 8 XCDs round-robin by linear id, so the C/span workgroups that
+                                    // read the same rows (16 B of every row each) land on Nb-spaced ids -- 2 XCDs at Nb = 4 instead of all 8
+                                    // (PMC: 3.6x the algorithmic bytes were fetched, every XCD's L2 pulling the lines for itself)
 #define DYCON_NFS_(SP, CP, RW) norm_fused_fwd_kernel<bf16, SP, CP, true, RW><<<grid, 256, 0, stream>>>((bf16*)x_out, (bf16*)y, V, C, G, eps, stats, gamma, beta, relu, (const bf16*)skip, chan_scale, nullptr, nullptr, 0.f, slab, splits, MN, conv_bias)
 #define DYCON_NFS(SP, CP) do { if (V <= 256) DYCON_NFS_(SP, CP, 1); else DYCON_NFS_(SP, CP, 8); } while (0)
     if (cpg == 1) DYCON_NFS(8, 1); else if (cpg == 2) DYCON_NFS(8, 2); else if (cpg == 4) DYCON_NFS(8, 4);
@@ -698,7 +700,7 @@ extern "C" int dycon_norm_fwd(const void* x, void* y, int dtype, int Nb, long lo
     if (norm_fused_ok(dtype, V, C, G)) {
         const int VN = dtype == DYCON_BF16 ? 8 : 4, cpg = C / G;
         const int span = cpg > VN ? cpg : VN;
-        dim3 grid(C / span, Nb);
+        dim3 grid(Nb, C / span);      // (x = sample: see dycon_norm_fwd_slab)
 #define DYCON_NF_(TT, SP, CP, RW) norm_fused_fwd_kernel<TT, SP, CP, false, RW><<<grid, 256, 0, stream>>>((TT*)const_cast<void*>(x), (TT*)y, V, C, G, eps, stats, gamma, beta, relu, (const TT*)skip, chan_scale, running_mean, running_var, momentum, nullptr, 0, 0, nullptr)
 #define DYCON_NF(TT, SP, CP) do { if (V <= 256) DYCON_NF_(TT, SP, CP, 1); else DYCON_NF_(TT, SP, CP, 8); } while (0)
         if (dtype == DYCON_BF16) {
@@ -817,7 +819,7 @@ extern "C" int dycon_norm_bwd_ex(const void* src, int from_y, const void* gy, vo
         const int VN = dtype == DYCON_BF16 ? 8 : 4, cpg = C / G;
         const int span = cpg > VN ? cpg : VN;
         const bool want = dgamma || dbeta;
-        dim3 grid(C / span, Nb);
+        dim3 grid(Nb, C / span);      // (x = sample: see dycon_norm_fwd_slab)
 #define DYCON_NB_(TT, SP, CP, RW) norm_fused_bwd_kernel<TT, SP, CP, RW><<<grid, 256, 0, stream>>>((const TT*)src, (const TT*)gy, (TT*)gx, V, C, G, stats, gamma, beta, relu, chan_scale, want ? workspace : nullptr)
 #define DYCON_NB(TT, SP, CP) do { if (V <= 256) DYCON_NB_(TT, SP, CP, 1); else DYCON_NB_(TT, SP, CP, 8); } while (0)
         if (dtype == DYCON_BF16) {

@@ -201,7 +201,7 @@ class Engine:
         self.fuse_head = True            # V-Net: the 2-class head inside the last normalisation's passes (_norm_head)
         self.conv_stats = False          # 48^3 level: the persistent convolution takes the statistics of its output (ops.conv_gemm_stats);
                                          # measured neutral for the step (+5 us per convolution against a 7 us statistics launch): off
-        self.conv_stats96 = True         # 96^3 level (conv_k3_c1 / conv_k3_p16): the same -- there the statistics pass re-reads 113 MB
+        self.conv_stats96 = False        # 96^3 level (conv_k3_c1 / conv_k3_p16): the same; measured neutral as well (TrainConfig.conv_stats96)
         self._stat_parts = {}
         self.fuse_first = True           # V-Net: block_one's norm backward formed on load by the first layer's weight gradient (_first_block)
         self.one_pass_first = True       # ... as ONE pass (dycon_first_block_bwd) instead of statistics + weight gradient

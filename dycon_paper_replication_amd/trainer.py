@@ -71,7 +71,9 @@ class TrainConfig:
     overlap_features: bool = True       # feature branch (projection head, embeddings, FeCL forward + backward) on its own stream
     split_repack: bool = True           # the student's weight repack off the head of the dependent chain (Engine.repack)
     conv_stats: bool = False            # 48^3 level: norm statistics taken by the persistent convolution (measured neutral: off)
-    conv_stats96: bool = True           # 96^3 level (block_one, block_nine): the same; saves a 113 MB statistics pass per site
+    conv_stats96: bool = False          # 96^3 level (block_one, block_nine): the same.  Saves a 113 MB statistics pass per site, but the
+                                        # epilogue costs the convolutions as much (conv_k3_c1 38 -> 78 us, conv_k3_p16 74 -> 90 us per launch
+                                        # against 4 x 20 us of statistics launches): step unchanged over three A/B pairs -- off
     one_pass_first: bool = True         # block_one's backward as one pass over (x, z, gy) (Engine.one_pass_first)
     fuse_first: bool = True             # V-Net: block_one's norm backward inside the first layer's weight gradient (Engine._first_block)
     fuse_head: bool = True              # V-Net: out_conv fused into block_nine's normalisation passes (Engine._norm_head)

@@ -302,3 +302,34 @@ def test_conv_takes_norm_statistics(cin, C, sp, kind):
     err = float((n.float() - n_ref.float()).abs().max())
     assert err <= 2.0 ** -7 * float(n_ref.float().abs().max()), err
     assert float((n != n_ref).float().mean()) < 1e-3
+
+
+def test_engine_with_producer_side_statistics():
+    """Engine.conv_stats / conv_stats96 (the persistent convolutions of the 48^3 and 96^3 levels hand the statistics of their output to the
+    normalisation that follows -- block_one through _first_block, block_nine through the fused norm + head): V-Net, bf16, B = 2 at 96^3,
+    forward and parameter gradients against the default launch sequence.  Same convolution outputs; the statistics differ in
+    summation order only, so the logits agree to bf16 round-off and the flat gradient keeps its direction."""
+    from dycon_paper_replication_amd.engine import Engine, param_spec, projection_buffers
+    p_all = ON.make_vnet_params(21)
+    spec = param_spec("vnet")
+    x = torch.randn(2, 96, 96, 96, 1, generator=torch.Generator().manual_seed(3)).to(DEV)
+    r1 = torch.randn(2, 96, 96, 96, 2, generator=torch.Generator().manual_seed(4)).to(DEV)
+    r2 = torch.randn(2, 12, 12, 12, 256, generator=torch.Generator().manual_seed(5)).to(DEV, BF)
+    res = []
+    for on in (False, True):
+        params = {k: p_all[k].to(DEV).contiguous() for k in spec}
+        grads = {k: torch.zeros_like(v) for k, v in params.items()}
+        bufs = {k: p_all[k].to(DEV) for k in projection_buffers()}
+        eng = Engine("vnet", params, grads, bufs, dtype=BF)
+        eng.conv_stats = eng.conv_stats96 = on
+        logits, feats, _ = eng.forward(x, training=True, record=True)
+        assert not eng._stat_parts                      # every partial a convolution left behind was consumed by its normalisation
+        lo, fe = logits.clone(), feats.float().clone()
+        eng.backward(r1, r2)
+        torch.cuda.synchronize()
+        res.append((lo, fe, torch.cat([grads[k].reshape(-1) for k in spec if not k.startswith("final.")]).double()))
+    (l0, f0, g0), (l1, f1, g1) = res
+    assert float((l1 - l0).abs().max()) <= 2e-2 * float(l0.abs().max())
+    assert float((f1 - f0).abs().max()) <= 4e-2 * float(f0.abs().max())
+    cos = float((g0 * g1).sum() / (g0.norm() * g1.norm()))
+    assert cos > 0.999 and 0.98 < float(g1.norm() / g0.norm()) < 1.02, cos

@@ -8,5 +8,5 @@ R=$GRAFT_REPO_ROOT
 for c in FETCH_SIZE WRITE_SIZE; do
   d=$(echo $c | tr 'A-Z' 'a-z' | sed 's/_size//')
   rocprofv3 --kernel-trace --pmc $c -d $R/gpurun_out/pmc_${tag}_$d -o run --output-format csv -- \
-    python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing > $R/gpurun_out/pmc_${tag}_$d.log 2>&1 || exit 1
+    python3 $R/bench.py --steps 2 --warmup 1 --repeats 1 --no-cpu-baseline --no-kernel-timing > $R/gpurun_out/pmc_${tag}_$d.log 2>&1 || exit 1
 done
