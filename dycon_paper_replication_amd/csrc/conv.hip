@@ -1841,8 +1841,12 @@ __device__ __forceinline__ bf16x8 tr_frag(const unsigned short* lds_lo, const un
     return __builtin_bit_cast(bf16x8, t);
 }
 
-template <int NT, bool CIN1>
-__global__ __launch_bounds__(256, 2) void wgrad_k3_bf16_kernel(const bf16* __restrict__ X, const bf16* __restrict__ GY,
+// NW = waves per workgroup: 4, or 8 where the grid gives a CU at most one workgroup (the 24^3 / 12^3 / 6^3 levels: <= 256 workgroups,
+// i.e. ONE wave per SIMD with nothing to hide its global-load, LDS and barrier latencies behind -- PMC: 42 % of a wave's life in
+// s_waitcnt / s_barrier, matrix pipe busy 21 %).  Eight waves split the 27 taps 4 / 3 instead of 7 / 6: half the accumulators per
+// wave, half the staging work per thread, two waves per SIMD.
+template <int NT, bool CIN1, int NW = 4>
+__global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void wgrad_k3_bf16_kernel(const bf16* __restrict__ X, const bf16* __restrict__ GY,
                                                             float* __restrict__ part, float* __restrict__ bias_part, int B, int D,
                                                             int H, int W, int Cin, int Cout, int nCoBlk, int nTiles, int tilesZ,
                                                             int tilesY, int tilesX) {
@@ -1853,10 +1857,11 @@ __global__ __launch_bounds__(256, 2) void wgrad_k3_bf16_kernel(const bf16* __res
     const int kg = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
     const int ci0 = (blockIdx.x / nCoBlk) * 16;
     const int co0 = (blockIdx.x % nCoBlk) * CB;
-    const int ntaps = wave < 3 ? 7 : 6;                 // taps wave, wave+4, ...
-    f32x4 acc[7][NT];
+    constexpr int NTHR = 64 * NW, TPW = (27 + NW - 1) / NW;      // taps per wave: wave, wave + NW, ...
+    const int ntaps = (27 - wave + NW - 1) / NW;
+    f32x4 acc[TPW][NT];
 #pragma unroll
-    for (int a = 0; a < 7; ++a)
+    for (int a = 0; a < TPW; ++a)
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[a][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     float bsum[NT];
@@ -1867,8 +1872,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_k3_bf16_kernel(const bf16* __res
     // Register-staged pipeline over this workgroup's tiles: the global loads of tile i+1 are issued before the MFMAs of tile i
     // and written to LDS after the barrier that retires tile i (the X halo and G tile of the next tile are in flight while
     // the matrix cores work).  CIN1 (first layer, one input channel): channel 0 carries x, channels 1..15 are zero.
-    constexpr int NSX = CIN1 ? (WG_NH + 255) / 256 : (WG_NH * 2 + 255) / 256;
-    constexpr int NSG = WG_NV * (CB / 8) / 256 > 0 ? WG_NV * (CB / 8) / 256 : 1;
+    constexpr int NSX = CIN1 ? (WG_NH + NTHR - 1) / NTHR : (WG_NH * 2 + NTHR - 1) / NTHR;
+    constexpr int NSG = (WG_NV * (CB / 8) + NTHR - 1) / NTHR;
     uint4 sx[NSX], sg[NSG];
     auto load_tile = [&](int tile) {
         int rr = tile;
@@ -1879,7 +1884,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_k3_bf16_kernel(const bf16* __res
         const int z0 = tz * WG_TZ, y0 = ty * WG_TY, x0 = tx * WG_TX;
 #pragma unroll
         for (int it = 0; it < NSX; ++it) {
-            const int e = threadIdx.x + 256 * it;
+            const int e = threadIdx.x + NTHR * it;
             const int hv = CIN1 ? e : e >> 1, half = CIN1 ? 0 : e & 1;
             const int hx = hv % WG_HX, hy = (hv / WG_HX) % WG_HY, hz = hv / (WG_HX * WG_HY);
             const int z = z0 + hz - 1, y = y0 + hy - 1, x = x0 + hx - 1;
@@ -1891,7 +1896,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_k3_bf16_kernel(const bf16* __res
         }
 #pragma unroll
         for (int it = 0; it < NSG; ++it) {
-            const int e = threadIdx.x + 256 * it;
+            const int e = threadIdx.x + NTHR * it;
             const int v8 = e % (CB / 8), vv = e / (CB / 8);
             const int vx = vv % WG_TX, vy = (vv / WG_TX) % WG_TY, vz = vv / (WG_TX * WG_TY);
             const int z = z0 + vz, y = y0 + vy, x = x0 + vx;
@@ -1903,7 +1908,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_k3_bf16_kernel(const bf16* __res
     auto store_tile = [&]() {
 #pragma unroll
         for (int it = 0; it < NSX; ++it) {
-            const int e = threadIdx.x + 256 * it;
+            const int e = threadIdx.x + NTHR * it;
             if (CIN1) {
                 if (e < WG_NH) {
                     *reinterpret_cast<uint4*>(Xh + e * 16) = sx[it];
@@ -1915,7 +1920,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_k3_bf16_kernel(const bf16* __res
         }
 #pragma unroll
         for (int it = 0; it < NSG; ++it) {
-            const int e = threadIdx.x + 256 * it;
+            const int e = threadIdx.x + NTHR * it;
             if (e < WG_NV * (CB / 8)) *reinterpret_cast<uint4*>(Gt + (e / (CB / 8)) * CB + 8 * (e % (CB / 8))) = sg[it];
         }
     };
@@ -1945,9 +1950,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_k3_bf16_kernel(const bf16* __res
                 }
             }
 #pragma unroll
-            for (int a = 0; a < 7; ++a) {
+            for (int a = 0; a < TPW; ++a) {
                 if (a < ntaps) {
-                    const int t = wave + 4 * a;
+                    const int t = wave + NW * a;
                     const int dz = t / 9, dy = (t / 3) % 3, dx = t % 3;
                     const unsigned short* a0 = Xh + (((z + dz) * WG_HY + (y + dy)) * WG_HX + q + dx) * 16 + 4 * p;
                     const bf16x8 afr = tr_frag(a0, a0 + 4 * 16);
@@ -1961,9 +1966,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_k3_bf16_kernel(const bf16* __res
     const int col = lane & 15;
     float* dst = part + (long long)blockIdx.y * 27 * Cin * Cout;
 #pragma unroll
-    for (int a = 0; a < 7; ++a) {
+    for (int a = 0; a < TPW; ++a) {
         if (a >= ntaps) continue;
-        const int t = wave + 4 * a;
+        const int t = wave + NW * a;
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
             const int co = co0 + 16 * j + col;
@@ -3551,7 +3556,10 @@ extern "C" int dycon_conv_wgrad(const void* x, int x_dtype, const void* gy, int 
         dim3 grid(k.gx, k.splits);
 #define DYCON_WK3(NTV, C1) \
     wgrad_k3_bf16_kernel<NTV, C1><<<grid, 256, 0, stream>>>((const bf16*)x, (const bf16*)gy, workspace, bpart, B, Di, Hi, Wi, Cin, Cout, k.nCoBlk, k.nTiles, k.tilesZ, k.tilesY, k.tilesX)
-        if (Cin == 1) { if (k.NT == 1) DYCON_WK3(1, true); else if (k.NT == 2) DYCON_WK3(2, true); else DYCON_WK3(4, true); }
+        static const bool wg_w8 = env_ll("DYCON_WGRAD_W8", 1) != 0;
+        if (wg_w8 && Cin != 1 && k.NT == 4 && (long long)k.gx * k.splits <= 256)      // at most one workgroup per CU: 8 waves, two per SIMD
+            wgrad_k3_bf16_kernel<4, false, 8><<<grid, 512, 0, stream>>>((const bf16*)x, (const bf16*)gy, workspace, bpart, B, Di, Hi, Wi, Cin, Cout, k.nCoBlk, k.nTiles, k.tilesZ, k.tilesY, k.tilesX);
+        else if (Cin == 1) { if (k.NT == 1) DYCON_WK3(1, true); else if (k.NT == 2) DYCON_WK3(2, true); else DYCON_WK3(4, true); }
         else if (k.NT == 1) DYCON_WK3(1, false);
         else if (k.NT == 2) DYCON_WK3(2, false);
         else DYCON_WK3(4, false);
