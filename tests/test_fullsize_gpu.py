@@ -329,7 +329,9 @@ def test_engine_with_producer_side_statistics():
         torch.cuda.synchronize()
         res.append((lo, fe, torch.cat([grads[k].reshape(-1) for k in spec if not k.startswith("final.")]).double()))
     (l0, f0, g0), (l1, f1, g1) = res
-    assert float((l1 - l0).abs().max()) <= 2e-2 * float(l0.abs().max())
-    assert float((f1 - f0).abs().max()) <= 4e-2 * float(f0.abs().max())
+    # (a statistic whose last bit differs moves single bf16 values of the first layers by one step, 2^-8; forty layers on, that is
+    #  1e-3 of the logits in the L2 norm and a few 1e-2 of their range at the worst voxel -- bf16 storage against fp32 is 8e-2 there)
+    assert float((l1 - l0).norm() / l0.norm()) <= 1e-2 and float((l1 - l0).abs().max()) <= 5e-2 * float(l0.abs().max())
+    assert float((f1 - f0).norm() / f0.norm()) <= 2e-2 and float((f1 - f0).abs().max()) <= 1e-1 * float(f0.abs().max())
     cos = float((g0 * g1).sum() / (g0.norm() * g1.norm()))
     assert cos > 0.999 and 0.98 < float(g1.norm() / g0.norm()) < 1.02, cos

@@ -2,7 +2,7 @@
 # round 3, GPU session 11: 8-wave weight-gradient workgroups at the small levels (A/B), XCD-local fused norms, engine statistics test
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/s11; mkdir -p $O
 cd $R
-timeout -k 10 900 python -m pytest tests/test_ops_gpu.py "tests/test_fullsize_gpu.py::test_conv_full_size_bf16" tests/test_fullsize_gpu.py::test_engine_with_producer_side_statistics tests/test_trainer_gpu.py tests/test_engine_gpu.py -x -q -m gpu > $O/pytest.log 2>&1 || { tail -40 $O/pytest.log; exit 1; }
+timeout -k 10 900 python -m pytest tests/test_ops_gpu.py "tests/test_fullsize_gpu.py::test_conv_full_size_bf16" tests/test_fullsize_gpu.py::test_engine_with_producer_side_statistics tests/test_trainer_gpu.py tests/test_engine_gpu.py -q -m gpu > $O/pytest.log 2>&1 || { tail -40 $O/pytest.log; exit 1; }
 tail -2 $O/pytest.log
 for v in 0 1; do for shp in "64 64 24" "128 128 12" "256 256 6"; do echo -n "DYCON_WGRAD_W8=$v  "; DYCON_WGRAD_W8=$v python tools/wgrad_micro.py $shp 30; done; done 2>&1 | grep -v amdgpu.ids | tee $O/wgrad_w8_micro.txt
 for i in 1 2 3; do for v in 0 1; do echo -n "DYCON_WGRAD_W8=$v  "; DYCON_WGRAD_W8=$v bash tools/variant_bench.sh dycon_paper_replication_amd/libdycon_hip.so; done; done 2>&1 | tee $O/variant_bench.txt
