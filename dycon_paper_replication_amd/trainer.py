@@ -18,6 +18,7 @@ from __future__ import annotations
 
 import contextlib
 import math
+import os
 from collections import OrderedDict
 from dataclasses import dataclass
 from typing import Dict, Optional
@@ -171,12 +172,28 @@ class DyconTrainer:
         # of the step, when the copy has long completed -- the host never waits for the backward, the GPU never runs dry
         self.flag_host = torch.zeros(1, dtype=torch.int32).pin_memory()
         self.flag_evt = torch.cuda.Event()
-        self.side = torch.cuda.Stream(device=self.device)
+        # DYCON_SIDE_PRIORITY (diagnostic): HIP priority of the side streams (teacher, weight gradients, features); 0 = default.
+        # A lower priority (positive number) for them was tried so that the student's chain wins the dispatch arbitration.
+        prio = int(os.environ.get("DYCON_SIDE_PRIORITY", "0"))
+
+        def side_stream():
+            if prio == 0:
+                return torch.cuda.Stream(device=self.device)
+            import ctypes
+            h = _lib.hip()
+            sp = ctypes.c_void_p()
+            h.hipStreamCreateWithPriority.restype = ctypes.c_int
+            h.hipStreamCreateWithPriority.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_uint, ctypes.c_int]
+            rc = h.hipStreamCreateWithPriority(ctypes.byref(sp), 1, prio)      # hipStreamNonBlocking
+            if rc:
+                raise RuntimeError(f"hipStreamCreateWithPriority({prio}) failed: {rc}")
+            return torch.cuda.ExternalStream(sp.value, device=self.device)
+        self.side = side_stream()
         if cfg.overlap_wgrad:
-            self.s_eng.wgrad_stream = torch.cuda.Stream(device=self.device)
+            self.s_eng.wgrad_stream = side_stream()
         # The feature branch -- projection head -> normalised embeddings -> FeCL, forward and backward -- meets the segmentation
         # branch only at the bottleneck tensor and in the scalar loss: it runs on a third stream, beside the decoder.
-        self.feat = torch.cuda.Stream(device=self.device) if cfg.overlap_features else None
+        self.feat = side_stream() if cfg.overlap_features else None
         # HIP multiplexes a process's streams onto 4 hardware queues.  The data-parallel run adds torch's collective stream: with
         # five or more busy streams two of them SHARE a queue and serialise (profiles/r03_ddp_one_rank_trace.txt: the teacher forward and
         # the weight-gradient launches, +0.28 ms/step), and raising GPU_MAX_HW_QUEUES to 8 oversubscribes the queues (7.4 ms/step).
