@@ -174,9 +174,10 @@ class DyconTrainer:
         self.flag_evt = torch.cuda.Event()
         # DYCON_SIDE_PRIORITY (diagnostic): HIP priority of the side streams (teacher, weight gradients, features); 0 = default.
         # A lower priority (positive number) for them was tried so that the student's chain wins the dispatch arbitration.
-        prio = int(os.environ.get("DYCON_SIDE_PRIORITY", "0"))
+        prios = [int(v) for v in os.environ.get("DYCON_SIDE_PRIORITY", "0").split(",")]
+        prios = (prios * 3)[:3] if len(prios) == 1 else (prios + [0, 0, 0])[:3]          # teacher, weight gradients, features
 
-        def side_stream():
+        def side_stream(prio):
             if prio == 0:
                 return torch.cuda.Stream(device=self.device)
             import ctypes
@@ -188,12 +189,12 @@ class DyconTrainer:
             if rc:
                 raise RuntimeError(f"hipStreamCreateWithPriority({prio}) failed: {rc}")
             return torch.cuda.ExternalStream(sp.value, device=self.device)
-        self.side = side_stream()
+        self.side = side_stream(prios[0])
         if cfg.overlap_wgrad:
-            self.s_eng.wgrad_stream = side_stream()
+            self.s_eng.wgrad_stream = side_stream(prios[1])
         # The feature branch -- projection head -> normalised embeddings -> FeCL, forward and backward -- meets the segmentation
         # branch only at the bottleneck tensor and in the scalar loss: it runs on a third stream, beside the decoder.
-        self.feat = side_stream() if cfg.overlap_features else None
+        self.feat = side_stream(prios[2]) if cfg.overlap_features else None
         # HIP multiplexes a process's streams onto 4 hardware queues.  The data-parallel run adds torch's collective stream: with
         # five or more busy streams two of them SHARE a queue and serialise (profiles/r03_ddp_one_rank_trace.txt: the teacher forward and
         # the weight-gradient launches, +0.28 ms/step), and raising GPU_MAX_HW_QUEUES to 8 oversubscribes the queues (7.4 ms/step).
