@@ -68,6 +68,7 @@ class TrainConfig:
     strict_nan_check: bool = True       # read the NaN/Inf flag every step, as the reference does
     global_batch_losses: bool = True    # DDP: all-reduce the Dice / FeCL-cross sums (exact global-batch semantics)
     overlap_teacher: bool = True        # teacher forward on a second HIP stream, concurrent with the student forward
+    teacher_priority: int = -1          # HIP priority of that stream (-1 high, 0 normal, 1 low): high measured 0.06 ms/step faster
     overlap_wgrad: bool = True          # weight-gradient launches of the backward on a second HIP stream (off the dgrad chain)
     overlap_features: bool = True       # feature branch (projection head, embeddings, FeCL forward + backward) on its own stream
     split_repack: bool = True           # the student's weight repack off the head of the dependent chain (Engine.repack)
@@ -172,10 +173,15 @@ class DyconTrainer:
         # of the step, when the copy has long completed -- the host never waits for the backward, the GPU never runs dry
         self.flag_host = torch.zeros(1, dtype=torch.int32).pin_memory()
         self.flag_evt = torch.cuda.Event()
-        # DYCON_SIDE_PRIORITY (diagnostic): HIP priority of the side streams (teacher, weight gradients, features); 0 = default.
-        # A lower priority (positive number) for them was tried so that the student's chain wins the dispatch arbitration.
-        prios = [int(v) for v in os.environ.get("DYCON_SIDE_PRIORITY", "0").split(",")]
-        prios = (prios * 3)[:3] if len(prios) == 1 else (prios + [0, 0, 0])[:3]          # teacher, weight gradients, features
+        # HIP priorities of the side streams (teacher, weight gradients, features).  Measured (profiles/r03_stream_priorities.txt, pairs on
+        # one box): the TEACHER's stream at high priority takes 0.06 ms off the step (4.90 -> 4.84 ms) -- its forward ends earlier and
+        # leaves the student's large levels alone sooner; high priority for the weight-gradient or feature stream returns nothing, low
+        # priority for the side streams costs 0.03 ms (and round 2 had the MAIN stream at high priority at 8.2 ms against 5.8).
+        # DYCON_SIDE_PRIORITY="t,w,f" overrides (diagnostic).
+        prios = [cfg.teacher_priority, 0, 0]
+        if os.environ.get("DYCON_SIDE_PRIORITY"):
+            prios = [int(v) for v in os.environ["DYCON_SIDE_PRIORITY"].split(",")]
+            prios = (prios * 3)[:3] if len(prios) == 1 else (prios + [0, 0, 0])[:3]
 
         def side_stream(prio):
             if prio == 0:
@@ -185,7 +191,8 @@ class DyconTrainer:
             sp = ctypes.c_void_p()
             h.hipStreamCreateWithPriority.restype = ctypes.c_int
             h.hipStreamCreateWithPriority.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_uint, ctypes.c_int]
-            rc = h.hipStreamCreateWithPriority(ctypes.byref(sp), 1, prio)      # hipStreamNonBlocking
+            with torch.cuda.device(self.device):
+                rc = h.hipStreamCreateWithPriority(ctypes.byref(sp), 1, prio)      # hipStreamNonBlocking
             if rc:
                 raise RuntimeError(f"hipStreamCreateWithPriority({prio}) failed: {rc}")
             return torch.cuda.ExternalStream(sp.value, device=self.device)
