@@ -181,6 +181,7 @@ class Engine:
         self.wgrad_stream = None     # optional side stream for the weight-gradient launches of the backward (set by the trainer)
         self.feat_stream = None      # optional stream for the feature branch (projection head forward + backward), see forward()
         self.mark = None             # optional callback(tag, stream): timeline marks (trainer._mark)
+        self.stage_hook = None       # optional callback(name): called in the V-Net forward when the encoder tensor `name` (x1..x5) is enqueued
         # per-step arena of zeroed doubles for the accumulator form of the norms (ops.norm_fwd / norm_bwd `acc`): slices are handed
         # out in call order; whoever owns the arena clears it once per step BEFORE the first norm (the trainer: one launch for both
         # nets; a stand-alone engine: at the start of forward()).
@@ -763,11 +764,17 @@ class Engine:
             x1 = self._first_block("block_one", x, nk, training)
         else:
             x1 = block("block_one", x, 1, first=True)
+        hook = self.stage_hook if self.stage_hook is not None else (lambda name: None)
+        hook("x1")
         self.pack_ready()            # (repack with early="block_one.": every other layer's operands were packed on a helper stream)
         x2 = block("block_two", down("block_one_dw", x1), 2)
+        hook("x2")
         x3 = block("block_three", down("block_two_dw", x2), 3)
+        hook("x3")
         x4 = block("block_four", down("block_three_dw", x3), 3)
+        hook("x4")
         x5 = block("block_five", down("block_four_dw", x4), 3, drop=("drop5", 0))   # + Dropout3d, VNet.py:195-196
+        hook("x5")
         x5_ready = self._mark_ready()
         u = up("block_five_up", x5, x4)
         u = up("block_six_up", block("block_six", u, 3), x3)

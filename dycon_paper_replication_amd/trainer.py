@@ -68,6 +68,8 @@ class TrainConfig:
     strict_nan_check: bool = True       # read the NaN/Inf flag every step, as the reference does
     global_batch_losses: bool = True    # DDP: all-reduce the Dice / FeCL-cross sums (exact global-batch semantics)
     overlap_teacher: bool = True        # teacher forward on a second HIP stream, concurrent with the student forward
+    teacher_after: Optional[str] = None # V-Net: start the teacher forward only when the student's encoder tensor x1..x5 is enqueued (phase shift
+                                        # of the two forwards: the teacher's HBM-bound top level beside the student's latency-bound deep levels)
     teacher_priority: int = -1          # HIP priority of that stream (-1 high, 0 normal, 1 low): high measured 0.06 ms/step faster
     overlap_wgrad: bool = True          # weight-gradient launches of the backward on a second HIP stream (off the dgrad chain)
     overlap_features: bool = True       # feature branch (projection head, embeddings, FeCL forward + backward) on its own stream
@@ -410,6 +412,22 @@ class DyconTrainer:
         if "teacher" in ABLATE:      # tools/ablate.py (timing experiment only)
             s_logits, s_feat, _ = self.s_eng.forward(x, training=True, record=True, dropout=s_drop, update_bn=True)
             t_logits, t_feat = s_logits, s_feat
+        elif c.overlap_teacher and c.teacher_after and c.model == "vnet":
+            # phase-shifted forwards: the student's is enqueued first and records an event when the chosen encoder tensor is enqueued;
+            # the teacher's weight packs start at once, its forward behind that event
+            side = self.side
+            ops.fork(main, side)
+            with ops.on_stream(self.side):
+                self.t_eng.repack()
+            gate = ops.Event()
+            self.s_eng.stage_hook = lambda name: gate.record(main) if name == c.teacher_after else None
+            s_logits, s_feat, _ = self.s_eng.forward(x, training=True, record=True, dropout=s_drop, update_bn=True)   # :304
+            self.s_eng.stage_hook = None
+            with ops.on_stream(self.side):
+                gate.wait(side)
+                t_logits, t_feat, _ = self.t_eng.forward(x_t, training=t_train, record=False, dropout=t_drop, update_bn=t_train)
+                self._mark("teacher_fwd_end")
+            x_t.record_stream(self.side)
         elif c.overlap_teacher:
             side = self.side
             ops.fork(main, side)
@@ -418,7 +436,7 @@ class DyconTrainer:
                 t_logits, t_feat, _ = self.t_eng.forward(x_t, training=t_train, record=False, dropout=t_drop, update_bn=t_train)
                 self._mark("teacher_fwd_end")
             x_t.record_stream(self.side)
-        if "teacher" not in ABLATE:
+        if "teacher" not in ABLATE and not (c.overlap_teacher and c.teacher_after and c.model == "vnet"):
             s_logits, s_feat, _ = self.s_eng.forward(x, training=True, record=True, dropout=s_drop, update_bn=True)   # :304
         if "teacher" in ABLATE:
             pass
