@@ -431,10 +431,17 @@ class DyconTrainer:
         elif c.overlap_teacher:
             side = self.side
             ops.fork(main, side)
+            head_start = os.environ.get("DYCON_STUDENT_AFTER")      # diagnostic: the student's forward waits for the teacher's x1..x5
+            gate = ops.Event() if head_start else None
             with ops.on_stream(self.side):
                 self.t_eng.repack()  # the teacher's packs belong to its stream (the EMA update that changed them precedes the fork)
+                if gate is not None:
+                    self.t_eng.stage_hook = lambda name: gate.record(side) if name == head_start else None
                 t_logits, t_feat, _ = self.t_eng.forward(x_t, training=t_train, record=False, dropout=t_drop, update_bn=t_train)
+                self.t_eng.stage_hook = None
                 self._mark("teacher_fwd_end")
+            if gate is not None:
+                gate.wait(main)
             x_t.record_stream(self.side)
         if "teacher" not in ABLATE and not (c.overlap_teacher and c.teacher_after and c.model == "vnet"):
             s_logits, s_feat, _ = self.s_eng.forward(x, training=True, record=True, dropout=s_drop, update_bn=True)   # :304

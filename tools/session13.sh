@@ -1,3 +1,3 @@
 #!/bin/bash
 R=$GRAFT_REPO_ROOT; cd $R
-timeout -k 10 900 python tools/ab.py "" "teacher_after='x1'" "teacher_after='x2'" "teacher_after='x3'" "teacher_after='x4'" "teacher_after='x5'" --reps 2 --steps 100 2>&1 | grep "ms/step" | tee gpurun_out/teacher_after.txt
+for i in 1 2; do for v in "" x1 x2 x3; do echo -n "DYCON_STUDENT_AFTER=$v  "; DYCON_STUDENT_AFTER=$v timeout -k 10 200 bash tools/variant_bench.sh dycon_paper_replication_amd/libdycon_hip.so; done; done 2>&1 | grep -v amdgpu.ids | tee gpurun_out/student_after.txt
