@@ -179,6 +179,8 @@ class Engine:
         self._jobs_split, self._pack_event = False, None
         self.on_param_grads = None   # optional callback(name): called in backward once a layer's parameter gradients are enqueued
         self.wgrad_stream = None     # optional side stream for the weight-gradient launches of the backward (set by the trainer)
+        self.wgrad_stream2 = None    # optional second one: the convolutions' weight gradients then alternate between the two
+        self._wg_flip = 0
         self.feat_stream = None      # optional stream for the feature branch (projection head forward + backward), see forward()
         self.mark = None             # optional callback(tag, stream): timeline marks (trainer._mark)
         self.stage_hook = None       # optional callback(name): called in the V-Net forward when the encoder tensor `name` (x1..x5) is enqueued
@@ -414,11 +416,16 @@ class Engine:
                     # The weight gradient only feeds the optimiser; the data gradient is the critical chain.  Enqueue the former on a
                     # second HIP stream (behind an event that marks gy ready) so the small-level wgrad / reduce launches fill the
                     # CUs the latency-bound dgrad / norm-backward kernels leave idle.  backward() joins the streams at the end.
-                    ops.fork(ops.cur_stream(), self.wgrad_stream)
-                    with ops.on_stream(self.wgrad_stream, light=True):
+                    wst = self.wgrad_stream
+                    if self.wgrad_stream2 is not None:
+                        self._wg_flip ^= 1
+                        if self._wg_flip:
+                            wst = self.wgrad_stream2
+                    ops.fork(ops.cur_stream(), wst)
+                    with ops.on_stream(wst, light=True):
                         self._flush_dparams()
                         wgrad(gy)
-                    gy.record_stream(self.wgrad_stream)
+                    gy.record_stream(wst)
                 else:
                     wgrad(gy)
                 if not need_gx:
@@ -908,4 +915,6 @@ class Engine:
             ops.fork(self.feat_stream, cs)
         if self.wgrad_stream is not None:
             ops.fork(self.wgrad_stream, cs)                   # all parameter gradients are complete behind this point
+            if self.wgrad_stream2 is not None:
+                ops.fork(self.wgrad_stream2, cs)
         self.tape, self.G = [], {}

@@ -203,6 +203,8 @@ class DyconTrainer:
             self.s_eng.wgrad_stream = side_stream(prios[1])
         # The feature branch -- projection head -> normalised embeddings -> FeCL, forward and backward -- meets the segmentation
         # branch only at the bottleneck tensor and in the scalar loss: it runs on a third stream, beside the decoder.
+        if cfg.overlap_wgrad and os.environ.get("DYCON_WGRAD_TWO_STREAMS") == "1" and not self.ddp:      # diagnostic: the teacher's stream is idle in the backward
+            self.s_eng.wgrad_stream2 = self.side
         self.feat = side_stream(prios[2]) if cfg.overlap_features else None
         # HIP multiplexes a process's streams onto 4 hardware queues.  The data-parallel run adds torch's collective stream: with
         # five or more busy streams two of them SHARE a queue and serialise (profiles/r03_ddp_one_rank_trace.txt: the teacher forward and

@@ -1,3 +1,4 @@
 #!/bin/bash
 R=$GRAFT_REPO_ROOT; cd $R
-for i in 1 2; do for v in "" x1 x2 x3; do echo -n "DYCON_STUDENT_AFTER=$v  "; DYCON_STUDENT_AFTER=$v timeout -k 10 200 bash tools/variant_bench.sh dycon_paper_replication_amd/libdycon_hip.so; done; done 2>&1 | grep -v amdgpu.ids | tee gpurun_out/student_after.txt
+timeout -k 10 300 python -m pytest tests/test_trainer_gpu.py -x -q -m gpu 2>&1 | tail -1
+for i in 1 2 3; do for v in 0 1; do echo -n "DYCON_WGRAD_TWO_STREAMS=$v  "; DYCON_WGRAD_TWO_STREAMS=$v bash tools/variant_bench.sh dycon_paper_replication_amd/libdycon_hip.so; done; done 2>&1 | grep -v amdgpu.ids | tee gpurun_out/wgrad_two_streams.txt
