@@ -72,6 +72,7 @@ class TrainConfig:
                                         # of the two forwards: the teacher's HBM-bound top level beside the student's latency-bound deep levels)
     teacher_priority: int = -1          # HIP priority of that stream (-1 high, 0 normal, 1 low): high measured 0.06 ms/step faster
     overlap_wgrad: bool = True          # weight-gradient launches of the backward on a second HIP stream (off the dgrad chain)
+    wgrad_two_streams: bool = True      # ... alternating with the teacher's stream, which is idle during the backward
     overlap_features: bool = True       # feature branch (projection head, embeddings, FeCL forward + backward) on its own stream
     split_repack: bool = True           # the student's weight repack off the head of the dependent chain (Engine.repack)
     conv_stats: bool = False            # 48^3 level: norm statistics taken by the persistent convolution (measured neutral: off)
@@ -203,7 +204,9 @@ class DyconTrainer:
             self.s_eng.wgrad_stream = side_stream(prios[1])
         # The feature branch -- projection head -> normalised embeddings -> FeCL, forward and backward -- meets the segmentation
         # branch only at the bottleneck tensor and in the scalar loss: it runs on a third stream, beside the decoder.
-        if cfg.overlap_wgrad and os.environ.get("DYCON_WGRAD_TWO_STREAMS") == "1" and not self.ddp:      # diagnostic: the teacher's stream is idle in the backward
+        # the teacher's stream is idle during the backward: the convolutions' weight gradients alternate between it and the weight-gradient
+        # stream (4.781 -> 4.755 ms/step over three pairs, profiles/r03_stream_priorities.txt); still four streams in all
+        if cfg.overlap_wgrad and cfg.overlap_teacher and cfg.wgrad_two_streams and os.environ.get("DYCON_WGRAD_TWO_STREAMS", "1") == "1":
             self.s_eng.wgrad_stream2 = self.side
         self.feat = side_stream(prios[2]) if cfg.overlap_features else None
         # HIP multiplexes a process's streams onto 4 hardware queues.  The data-parallel run adds torch's collective stream: with
@@ -254,7 +257,10 @@ class DyconTrainer:
             # collective is issued from the WEIGHT-GRADIENT stream, which first waits for the other two: that stream trails the chain
             # it is forked from, so the waits are free, and the data-gradient chain on main never waits for anything in mid-backward.
             issuer = self.s_eng.wgrad_stream if self.s_eng.wgrad_stream is not None else self._main
-            others = [o for o in (self._main, self.feat, self.s_eng.wgrad_stream) if o is not None and o != issuer]
+            others = []
+            for o in (self._main, self.feat, self.s_eng.wgrad_stream, self.s_eng.wgrad_stream2):
+                if o is not None and o != issuer and o not in others:
+                    others.append(o)
             evs = [torch.cuda.Event() for _ in others]
             view = self.flat_g[rng[0]:rng[1]]
 
