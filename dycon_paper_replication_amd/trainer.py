@@ -208,6 +208,11 @@ class DyconTrainer:
         # stream (4.781 -> 4.755 ms/step over three pairs, profiles/r03_stream_priorities.txt); still four streams in all
         if cfg.overlap_wgrad and cfg.overlap_teacher and cfg.wgrad_two_streams and os.environ.get("DYCON_WGRAD_TWO_STREAMS", "1") == "1":
             self.s_eng.wgrad_stream2 = self.side
+        # the teacher's projection head depends on its bottleneck only: it runs beside the teacher's decoder on the weight-gradient
+        # stream (idle during the forwards), so the teacher's chain ends one head earlier
+        if (cfg.overlap_teacher and cfg.overlap_features and self.s_eng.wgrad_stream is not None
+                and os.environ.get("DYCON_TEACHER_HEAD_STREAM", "1") == "1"):
+            self.t_eng.feat_stream = self.s_eng.wgrad_stream
         self.feat = side_stream(prios[2]) if cfg.overlap_features else None
         # HIP multiplexes a process's streams onto 4 hardware queues.  The data-parallel run adds torch's collective stream: with
         # five or more busy streams two of them SHARE a queue and serialise (profiles/r03_ddp_one_rank_trace.txt: the teacher forward and
@@ -442,7 +447,12 @@ class DyconTrainer:
             head_start = os.environ.get("DYCON_STUDENT_AFTER")      # diagnostic: the student's forward waits for the teacher's x1..x5
             gate = ops.Event() if head_start else None
             with ops.on_stream(self.side):
-                self.t_eng.repack()  # the teacher's packs belong to its stream (the EMA update that changed them precedes the fork)
+                # the teacher's packs belong to its stream (the EMA update that changed them precedes the fork); like the student's they
+                # are split: block_one's operands in front of the first convolution, the rest on an idle stream
+                if c.split_repack and self.feat is not None and self.feat is not self.side and os.environ.get("DYCON_TEACHER_SPLIT_PACK", "1") == "1":
+                    self.t_eng.repack(early="block_one.", helper=self.feat)
+                else:
+                    self.t_eng.repack()
                 if gate is not None:
                     self.t_eng.stage_hook = lambda name: gate.record(side) if name == head_start else None
                 t_logits, t_feat, _ = self.t_eng.forward(x_t, training=t_train, record=False, dropout=t_drop, update_bn=t_train)
@@ -481,6 +491,8 @@ class DyconTrainer:
                 feat, src = self.feat, (self.side if c.overlap_teacher else main)
                 ops.fork(src, feat)
                 t_feat.record_stream(self.feat)
+                if self.t_eng.feat_stream is not None and self.t_eng.feat_stream is not src:
+                    ops.fork(self.t_eng.feat_stream, feat)      # (the teacher's projection head ran beside its decoder)
             s_emb, s_nrm = ops.l2norm_fwd(s_feat.reshape(B, -1, s_feat.shape[-1]))          # :316-319
             t_emb, _ = ops.l2norm_fwd(t_feat.reshape(B, -1, t_feat.shape[-1]))              # :321-323
             k = (D // s_feat.shape[1], H // s_feat.shape[2], W // s_feat.shape[3])
