@@ -180,6 +180,7 @@ class Engine:
         self.on_param_grads = None   # optional callback(name): called in backward once a layer's parameter gradients are enqueued
         self.wgrad_stream = None     # optional side stream for the weight-gradient launches of the backward (set by the trainer)
         self.wgrad_stream2 = None    # optional second one: the convolutions' weight gradients then alternate between the two
+        self.wgrad_stream3 = None    # (diagnostic) a third
         self._wg_flip = 0
         self.feat_stream = None      # optional stream for the feature branch (projection head forward + backward), see forward()
         self.mark = None             # optional callback(tag, stream): timeline marks (trainer._mark)
@@ -418,9 +419,9 @@ class Engine:
                     # CUs the latency-bound dgrad / norm-backward kernels leave idle.  backward() joins the streams at the end.
                     wst = self.wgrad_stream
                     if self.wgrad_stream2 is not None:
-                        self._wg_flip ^= 1
-                        if self._wg_flip:
-                            wst = self.wgrad_stream2
+                        ring = [self.wgrad_stream, self.wgrad_stream2] + ([self.wgrad_stream3] if self.wgrad_stream3 is not None else [])
+                        self._wg_flip = (self._wg_flip + 1) % len(ring)
+                        wst = ring[self._wg_flip]
                     ops.fork(ops.cur_stream(), wst)
                     with ops.on_stream(wst, light=True):
                         self._flush_dparams()
@@ -917,4 +918,6 @@ class Engine:
             ops.fork(self.wgrad_stream, cs)                   # all parameter gradients are complete behind this point
             if self.wgrad_stream2 is not None:
                 ops.fork(self.wgrad_stream2, cs)
+            if self.wgrad_stream3 is not None and self.wgrad_stream3 is not self.feat_stream:
+                ops.fork(self.wgrad_stream3, cs)
         self.tape, self.G = [], {}

@@ -223,6 +223,8 @@ class DyconTrainer:
         if self.ddp and self.feat is not None and cfg.overlap_teacher:
             self.feat = self.side
         self.s_eng.feat_stream = self.feat
+        if self.s_eng.wgrad_stream2 is not None and self.feat is not None and os.environ.get("DYCON_WGRAD_THREE_STREAMS") == "1":
+            self.s_eng.wgrad_stream3 = self.feat        # (diagnostic)
         self.marks = None            # see _mark
         self._rp = None              # recorded step: dict(sig, rec, by_name, it, out, vol, lab)
         self._eager_seen = {}
@@ -447,9 +449,9 @@ class DyconTrainer:
             head_start = os.environ.get("DYCON_STUDENT_AFTER")      # diagnostic: the student's forward waits for the teacher's x1..x5
             gate = ops.Event() if head_start else None
             with ops.on_stream(self.side):
-                # the teacher's packs belong to its stream (the EMA update that changed them precedes the fork); like the student's they
-                # are split: block_one's operands in front of the first convolution, the rest on an idle stream
-                if c.split_repack and self.feat is not None and self.feat is not self.side and os.environ.get("DYCON_TEACHER_SPLIT_PACK", "1") == "1":
+                # the teacher's packs belong to its stream (the EMA update that changed them precedes the fork).  Splitting them like the
+                # student's (block_one's operands first, the rest on an idle stream) measured neutral to +0.01 ms: off (DYCON_TEACHER_SPLIT_PACK)
+                if c.split_repack and self.feat is not None and self.feat is not self.side and os.environ.get("DYCON_TEACHER_SPLIT_PACK", "0") == "1":
                     self.t_eng.repack(early="block_one.", helper=self.feat)
                 else:
                     self.t_eng.repack()
