@@ -491,10 +491,15 @@ class DyconTrainer:
         with fctx():
             if self.feat is not None:                     # teacher features (the student's head was enqueued on self.feat)
                 feat, src = self.feat, (self.side if c.overlap_teacher else main)
-                ops.fork(src, feat)
-                t_feat.record_stream(self.feat)
                 if self.t_eng.feat_stream is not None and self.t_eng.feat_stream is not src:
-                    ops.fork(self.t_eng.feat_stream, feat)      # (the teacher's projection head ran beside its decoder)
+                    # the teacher's projection head ran beside its decoder on another stream: the embeddings and FeCL wait for THAT
+                    # stream only, not for the end of the teacher's forward, and start while both decoders are still in their deep levels
+                    ops.fork(self.t_eng.feat_stream, feat)
+                    if os.environ.get("DYCON_FECL_EARLY", "1") != "1":
+                        ops.fork(src, feat)
+                else:
+                    ops.fork(src, feat)
+                t_feat.record_stream(self.feat)
             s_emb, s_nrm = ops.l2norm_fwd(s_feat.reshape(B, -1, s_feat.shape[-1]))          # :316-319
             t_emb, _ = ops.l2norm_fwd(t_feat.reshape(B, -1, t_feat.shape[-1]))              # :321-323
             k = (D // s_feat.shape[1], H // s_feat.shape[2], W // s_feat.shape[3])
