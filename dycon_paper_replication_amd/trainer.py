@@ -537,8 +537,11 @@ class DyconTrainer:
         if self.feat is not None:
             ops.fork(main, feat)       # coef (and, with DDP, the all-reduced FeCL sums)
         with fctx():
-            g_emb = ops.fecl_bwd(*fargs, float(gw), fst, self.coef[5:6])
-            g_feat = ops.l2norm_bwd(s_emb, s_nrm, g_emb).reshape(s_feat.shape)
+            if "feat_bwd" in ABLATE:     # tools/ablate.py (timing only): the feature branch's loss backward switched off
+                g_feat = torch.zeros_like(s_feat)
+            else:
+                g_emb = ops.fecl_bwd(*fargs, float(gw), fst, self.coef[5:6])
+                g_feat = ops.l2norm_bwd(s_emb, s_nrm, g_emb).reshape(s_feat.shape)
         self.s_eng.backward(g_logits, g_feat)            # head entries replay on self.feat, joins at the bottleneck gradient
 
         # ---- all-reduce, clip, SGD, EMA (:368-372)
