@@ -176,7 +176,7 @@ class DyconTrainer:
         # of the step, when the copy has long completed -- the host never waits for the backward, the GPU never runs dry
         self.flag_host = torch.zeros(1, dtype=torch.int32).pin_memory()
         self.flag_evt = torch.cuda.Event()
-        # HIP priorities of the side streams (teacher, weight gradients, features).  Measured (profiles/r03_stream_priorities.txt, pairs on
+        # HIP priorities of the side streams (teacher, weight gradients, features).  Measured (profiles/r03_stream_scheduling.txt, pairs on
         # one box): the TEACHER's stream at high priority takes 0.06 ms off the step (4.90 -> 4.84 ms) -- its forward ends earlier and
         # leaves the student's large levels alone sooner; high priority for the weight-gradient or feature stream returns nothing, low
         # priority for the side streams costs 0.03 ms (and round 2 had the MAIN stream at high priority at 8.2 ms against 5.8).
@@ -205,7 +205,7 @@ class DyconTrainer:
         # The feature branch -- projection head -> normalised embeddings -> FeCL, forward and backward -- meets the segmentation
         # branch only at the bottleneck tensor and in the scalar loss: it runs on a third stream, beside the decoder.
         # the teacher's stream is idle during the backward: the convolutions' weight gradients alternate between it and the weight-gradient
-        # stream (4.781 -> 4.755 ms/step over three pairs, profiles/r03_stream_priorities.txt); still four streams in all
+        # stream (4.781 -> 4.755 ms/step over three pairs, profiles/r03_stream_scheduling.txt); still four streams in all
         if cfg.overlap_wgrad and cfg.overlap_teacher and cfg.wgrad_two_streams and os.environ.get("DYCON_WGRAD_TWO_STREAMS", "1") == "1":
             self.s_eng.wgrad_stream2 = self.side
         # the teacher's projection head depends on its bottleneck only: it runs beside the teacher's decoder on the weight-gradient
@@ -492,10 +492,11 @@ class DyconTrainer:
             if self.feat is not None:                     # teacher features (the student's head was enqueued on self.feat)
                 feat, src = self.feat, (self.side if c.overlap_teacher else main)
                 if self.t_eng.feat_stream is not None and self.t_eng.feat_stream is not src:
-                    # the teacher's projection head ran beside its decoder on another stream: the embeddings and FeCL wait for THAT
-                    # stream only, not for the end of the teacher's forward, and start while both decoders are still in their deep levels
+                    # the teacher's projection head ran beside its decoder on another stream.  The embeddings and FeCL still wait for the
+                    # END of the teacher's forward as well: starting them as soon as the head is done (DYCON_FECL_EARLY=1, i.e. while both
+                    # decoders are in their latency-bound deep levels) measured 0.04 ms SLOWER than beside the student's HBM-bound top level
                     ops.fork(self.t_eng.feat_stream, feat)
-                    if os.environ.get("DYCON_FECL_EARLY", "1") != "1":
+                    if os.environ.get("DYCON_FECL_EARLY", "0") != "1":
                         ops.fork(src, feat)
                 else:
                     ops.fork(src, feat)
