@@ -181,9 +181,6 @@ class Engine:
         self.wgrad_stream = None     # optional side stream for the weight-gradient launches of the backward (set by the trainer)
         self.wgrad_stream2 = None    # optional second one: the convolutions' weight gradients then alternate between the two
         self.wgrad_stream3 = None    # (diagnostic) a third
-        dw = os.environ.get("DYCON_DEFER_WGRAD", "")
-        self.defer_wgrad = tuple(dw.split(",")) if dw else None      # (diagnostic) see _conv
-        self._late_wgrads = []
         self._wg_flip = 0
         self.feat_stream = None      # optional stream for the feature branch (projection head forward + backward), see forward()
         self.mark = None             # optional callback(tag, stream): timeline marks (trainer._mark)
@@ -416,15 +413,7 @@ class Engine:
                 elif "wgrad_no_events" in ABLATE and self.wgrad_stream is not None:        # the kernels, without the fork (a race: timing only)
                     with ops.on_stream(self.wgrad_stream, light=True):
                         wgrad(gy)
-                elif self.wgrad_stream is not None and self.defer_wgrad and name.startswith(self.defer_wgrad[0]):
-                    # (diagnostic, DYCON_DEFER_WGRAD="from,until") this layer's weight gradient is enqueued later, when the backward
-                    # reaches the layer `until`: the top level's data-gradient kernels then run beside fewer HBM-bound side-stream launches
-                    ev = ops.Event()
-                    ev.record(ops.cur_stream())
-                    self._late_wgrads.append((ev, gy, wgrad))
                 elif self.wgrad_stream is not None:
-                    if self._late_wgrads and name.startswith(self.defer_wgrad[1]):
-                        self._flush_late_wgrads()
                     # The weight gradient only feeds the optimiser; the data gradient is the critical chain.  Enqueue the former on a
                     # second HIP stream (behind an event that marks gy ready) so the small-level wgrad / reduce launches fill the
                     # CUs the latency-bound dgrad / norm-backward kernels leave idle.  backward() joins the streams at the end.
@@ -477,15 +466,6 @@ class Engine:
         a = self.acc_arena[self._acc_off:self._acc_off + n]
         self._acc_off += n
         return a
-
-    def _flush_late_wgrads(self):
-        for ev, gy, wgrad in self._late_wgrads:
-            wst = self.wgrad_stream2 if self.wgrad_stream2 is not None else self.wgrad_stream
-            ev.wait(wst)
-            with ops.on_stream(wst, light=True):
-                wgrad(gy)
-            gy.record_stream(wst)
-        self._late_wgrads = []
 
     def _flush_dparams(self):
         """deferred dgamma / dbeta sums of the norms whose backward has been enqueued (call inside the weight-gradient section)"""
@@ -921,8 +901,6 @@ class Engine:
                     self.tape[i]()
             else:
                 self.tape[i]()
-        if self._late_wgrads:
-            self._flush_late_wgrads()
         cs = ops.cur_stream()
         if self._pending_dparams:                             # (a norm whose convolution does not run its weight gradient on the side stream)
             ops.fork(cs, self.wgrad_stream)
