@@ -163,3 +163,28 @@ def test_ddp_oracle_step_consistency():
     for k in ("block_one.conv.0.weight", "block_nine.conv.0.weight", "out_conv.weight"):
         np.testing.assert_allclose(states[0].student[k].numpy(), g.student[k].numpy(), rtol=1e-4, atol=1e-6, err_msg=k)
         assert torch.equal(states[0].student[k], states[1].student[k])
+
+
+@pytest.mark.parametrize("net", ["vnet", "unet_3D"])
+def test_gradient_bucket_cuts(net):
+    """The bucket that completes LAST in the backward (the one starting at arena offset 0) is small, the cuts are parameter
+    boundaries in ascending order and the buckets tile [0, n_sgd) -- on the real parameter layouts."""
+    import math
+    from dycon_paper_replication_amd.engine import param_spec
+    from dycon_paper_replication_amd.trainer import bucket_cuts
+    spec = param_spec(net, 1, 2, "groupnorm")
+    order = [k for k in spec if not k.startswith("final.")]
+    offs, off = {}, 0
+    for k in order:
+        offs[k] = off
+        off += (int(math.prod(spec[k])) + 3) // 4 * 4
+    heads = [offs[k] for k in order if len(spec[k]) == 5]
+    cuts = bucket_cuts(heads, off, nb=4, tail_frac=0.06)
+    assert cuts[0] == 0 and cuts[-1] == off and cuts == sorted(set(cuts)) and 3 <= len(cuts) <= 5
+    assert all(c in heads for c in cuts[:-1])
+    assert 0 < cuts[1] <= 0.06 * off                                      # the exposed transfer: at most 6 % of the arena
+    sizes = np.diff(cuts)[1:]
+    assert sizes.max() <= 0.62 * (off - cuts[1])                          # no remaining bucket dominates (one 3^3 layer of the deepest level is ~19-28 %)
+    # degenerate inputs
+    assert bucket_cuts([0], 100) == [0, 100]
+    assert bucket_cuts([0, 50], 100, nb=2) == [0, 50, 100]
