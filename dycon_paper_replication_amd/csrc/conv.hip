@@ -289,19 +289,28 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const T* __restrict__ X,
 // the next k-step's global loads in flight under the MFMAs.  Split-K partial slabs + ordered finish as in conv_gemm_kernel.
 // ------------------------------------------------------------------------------------------------
 constexpr int CT_BM = 64, CT_BN = 128, CT_AS = 40;          // A rows padded to 80 B: conflict-free ds_read_b128 fragments
+constexpr int CT_OS = CT_BN + 4;                            // fp32 row stride of the slab epilogue's LDS image (528 B: the four row
+                                                            // groups of a D fragment land 16 banks apart)
 
 // KS2 = 32-channel chunks per k-step (1 or 2).  With one chunk per step a wave issues 8 MFMAs (128 matrix cycles) between two barriers
 // and pays, per step, a publish, a request and ~70 scalar instructions of address bookkeeping: PMC (profiles/r03_pmc_small_levels.txt)
 // has 1935 SALU + 1158 VALU instructions per wave against 216 MFMAs, the matrix pipe busy 8.5 % of a wave's life and 42 % of it spent
 // in s_waitcnt / s_barrier.  KS2 = 2 (Cin % 64 == 0: the V-Net's 128- and 256-channel levels) halves the number of steps: 16 MFMAs
 // per barrier, two chunks of the same tap requested with one address computation (LDS 52 KB per workgroup: 3 per CU).
+#ifndef CT_DIAG
+#define CT_DIAG 0     // timing diagnostics only (wrong results): 1 no A loads, 2 no B loads, 4 no slab stores, 8 no MFMAs (bit mask)
+#endif
 template <int KS2>
 __global__ __launch_bounds__(256, KS2 == 1 ? 4 : 3) void conv_k3_tile_kernel(const bf16* __restrict__ X, const bf16* __restrict__ Wf,
                                                            const float* __restrict__ bias, bf16* __restrict__ Y,
                                                            float* __restrict__ slab, int B, int D, int H, int W, int Cin, int N,
                                                            int NT, int nKC, int kc_per_split, int accumulate, int span_major = 0) {
-    __shared__ __attribute__((aligned(16))) unsigned short As[2][KS2][CT_BM * CT_AS];
-    __shared__ __attribute__((aligned(16))) unsigned short Bs[2][KS2][8 * 64 * 8];
+    // one LDS block: the double-buffered A / B tiles of the k-loop, re-used by the slab epilogue as a 64 x 128 fp32 image
+    constexpr int A_ELEMS = CT_BM * CT_AS, B_ELEMS = 8 * 64 * 8;
+    constexpr int KLOOP_BYTES = 2 * KS2 * (A_ELEMS + B_ELEMS) * 2, EPI_BYTES = CT_BM * CT_OS * 4;
+    __shared__ __attribute__((aligned(16))) unsigned char lds_raw[KLOOP_BYTES > EPI_BYTES ? KLOOP_BYTES : EPI_BYTES];
+    unsigned short (*As)[KS2][A_ELEMS] = reinterpret_cast<unsigned short (*)[KS2][A_ELEMS]>(lds_raw);
+    unsigned short (*Bs)[KS2][B_ELEMS] = reinterpret_cast<unsigned short (*)[KS2][B_ELEMS]>(lds_raw + 2 * KS2 * A_ELEMS * 2);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 15, kg = lane >> 4;
     const int wm = wave >> 1, wn = wave & 1;
@@ -345,9 +354,11 @@ __global__ __launch_bounds__(256, KS2 == 1 ? 4 : 3) void conv_k3_tile_kernel(con
 #pragma unroll
         for (int u = 0; u < KS2; ++u) {                          // the chunks of a step share the tap: channels c + 32 u
             st.a[u] = make_uint4(0, 0, 0, 0);
-            if (in && kreq + u < kc1) st.a[u] = *reinterpret_cast<const uint4*>(xs + aoff + 64 * u);
-            st.b0[u] = *reinterpret_cast<const uint4*>(ws + (long long)u * NT * 1024 + boff);
-            st.b1[u] = *reinterpret_cast<const uint4*>(ws + (long long)u * NT * 1024 + boff + 4096);
+            if (!(CT_DIAG & 1) && in && kreq + u < kc1) st.a[u] = *reinterpret_cast<const uint4*>(xs + aoff + 64 * u);
+            if (!(CT_DIAG & 2) || kreq == kc0) {
+                st.b0[u] = *reinterpret_cast<const uint4*>(ws + (long long)u * NT * 1024 + boff);
+                st.b1[u] = *reinterpret_cast<const uint4*>(ws + (long long)u * NT * 1024 + boff + 4096);
+            }
         }
         kreq += KS2;
         c += 32 * KS2;
@@ -379,7 +390,10 @@ __global__ __launch_bounds__(256, KS2 == 1 ? 4 : 3) void conv_k3_tile_kernel(con
 #pragma unroll
             for (int m = 0; m < 2; ++m)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[m][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[m], b[j], acc[m][j], 0, 0, 0);
+                for (int j = 0; j < 4; ++j) {
+                    if (CT_DIAG & 8) acc[m][j][0] += (float)a[m][0] * (float)b[j][0];
+                    else acc[m][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[m], b[j], acc[m][j], 0, 0, 0);
+                }
         }
     };
 
@@ -396,7 +410,31 @@ __global__ __launch_bounds__(256, KS2 == 1 ? 4 : 3) void conv_k3_tile_kernel(con
         compute(1); publish(s0, 0); request(s0); __syncthreads();
     }
     // epilogue.  D layout of a 16x16 tile: column = lane & 15, row = 4 * (lane >> 4) + i
-    if (slab) {
+    if (slab && span_major == 0) {
+        // Partial slab [row][N] fp32: a lane-per-element epilogue writes 64-byte pieces of four rows per store instruction (measured:
+        // 7 of the 27 us of a 128 -> 128 @ 12^3 launch + finish, profiles/r03_conv_tile_bounds.txt).  The tile goes through LDS
+        // (the k-loop's buffers are free: the loop ends on a barrier) and leaves as 16-byte pieces, two whole 512-byte rows per wave
+        // instruction -- with N = 128 the workgroup's 64 rows are one contiguous 32 KB run of the slab.
+        float* Ot = reinterpret_cast<float*>(lds_raw);
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) Ot[(wm * 32 + m * 16 + kg * 4 + i) * CT_OS + (wn * 4 + j) * 16 + r] = acc[m][j][i];
+        __syncthreads();
+        float* sl = slab + (long long)blockIdx.z * M * N + (long long)blockIdx.x * CT_BM * N + nt0 * 16;
+        const long long rows = min((long long)CT_BM, M - (long long)blockIdx.x * CT_BM);
+#pragma unroll
+        for (int e = threadIdx.x; e < CT_BM * (CT_BN / 4); e += 256) {
+            const int row = e / (CT_BN / 4), pc = e % (CT_BN / 4);
+            if (row < rows && !(CT_DIAG & 4))
+                *reinterpret_cast<float4*>(sl + (long long)row * N + pc * 4) = *reinterpret_cast<const float4*>(Ot + row * CT_OS + pc * 4);
+        }
+        return;
+    }
+    if (slab) {                                                // span_major 1: span-major slabs (finish deferred to the one-launch norm); 2: the
+                                                               // lane-per-element row-major epilogue (DYCON_TILE_LDS_EPI=0, kept for A/B timing)
         float* sl = slab + (long long)blockIdx.z * M * N;
 #pragma unroll
         for (int m = 0; m < 2; ++m)
@@ -407,7 +445,7 @@ __global__ __launch_bounds__(256, KS2 == 1 ? 4 : 3) void conv_k3_tile_kernel(con
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int n = (nt0 + wn * 4 + j) * 16 + r;
-                    if (n < N) sl[span_major ? ((long long)(n >> 3) * M + mo) * 8 + (n & 7) : mo * N + n] = acc[m][j][i];
+                    if (n < N) sl[span_major == 1 ? ((long long)(n >> 3) * M + mo) * 8 + (n & 7) : mo * N + n] = acc[m][j][i];
                 }
             }
         return;
@@ -1833,6 +1871,10 @@ constexpr int WG_TZ = 4, WG_TY = 4, WG_TX = 8;                       // voxel ti
 constexpr int WG_HZ = WG_TZ + 2, WG_HY = WG_TY + 2, WG_HX = WG_TX + 2;   // halo tile
 constexpr int WG_NV = WG_TZ * WG_TY * WG_TX;                          // 128 voxels = 4 MFMA k-steps
 constexpr int WG_NH = WG_HZ * WG_HY * WG_HX;                          // 360 halo voxels
+#ifndef WG_PAD
+#define WG_PAD 1     // 0: natural LDS pitches (A/B timing builds)
+#endif
+constexpr int WG_XP = WG_PAD ? 12 : WG_HX;                                             // x pitch of the halo's LDS image (voxels): see wgrad_k3_bf16_kernel
 
 __device__ __forceinline__ bf16x8 tr_frag(const unsigned short* lds_lo, const unsigned short* lds_hi) {
     const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)lds_lo);
@@ -1851,8 +1893,17 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void wgrad_k3_bf16_kernel
                                                             int H, int W, int Cin, int Cout, int nCoBlk, int nTiles, int tilesZ,
                                                             int tilesY, int tilesX) {
     constexpr int CB = 16 * NT;
-    __shared__ __attribute__((aligned(16))) unsigned short Xh[WG_NH * 16];
-    __shared__ __attribute__((aligned(16))) unsigned short Gt[WG_NV * CB];
+    // LDS images laid out for the transposed reads (ds_read_b64_tr_b16: banks = dword address mod 64, lanes 0-31 and 32-63 served
+    // separately; a lane group = 2 x-rows (kg) x 4 voxels (q) x 4 channel quads (p) of 8 bytes, so the 8 (kg, q) blocks must start
+    // at 8 distinct multiples of 8 dwords mod 64).  Natural pitches put them on top of each other -- PMC had 44-57 % of the LDS
+    // cycles as bank conflicts (profiles/r03_pmc_small_levels.txt):
+    //   X halo: 8 dwords per voxel (q -> 0, 8, 16, 24); x pitch padded from 10 to 12 voxels = 96 dwords (kg -> +32)
+    //   G tile: voxel stride GVS (NT = 4: 40 dwords, q -> 0, 40, 16, 56; else the natural 8 NT), row stride GRS = 8 GVS + pad = 32
+    //           (NT = 2: 8) mod 64 dwords
+    constexpr int GVS = WG_PAD && NT == 4 ? 80 : CB;             // elements
+    constexpr int GRS = 8 * GVS + (!WG_PAD ? 0 : NT == 2 ? 16 : 64);
+    __shared__ __attribute__((aligned(16))) unsigned short Xh[WG_HZ * WG_HY * WG_XP * 16];
+    __shared__ __attribute__((aligned(16))) unsigned short Gt[(WG_NV / 8) * GRS];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int kg = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
     const int ci0 = (blockIdx.x / nCoBlk) * 16;
@@ -1909,19 +1960,22 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void wgrad_k3_bf16_kernel
 #pragma unroll
         for (int it = 0; it < NSX; ++it) {
             const int e = threadIdx.x + NTHR * it;
+            const int hv = CIN1 ? e : e >> 1;
+            const int lv = (hv / WG_HX) * WG_XP + hv % WG_HX;     // halo voxel -> padded LDS voxel
             if (CIN1) {
                 if (e < WG_NH) {
-                    *reinterpret_cast<uint4*>(Xh + e * 16) = sx[it];
-                    *reinterpret_cast<uint4*>(Xh + e * 16 + 8) = make_uint4(0, 0, 0, 0);
+                    *reinterpret_cast<uint4*>(Xh + lv * 16) = sx[it];
+                    *reinterpret_cast<uint4*>(Xh + lv * 16 + 8) = make_uint4(0, 0, 0, 0);
                 }
             } else if (e < WG_NH * 2) {
-                *reinterpret_cast<uint4*>(Xh + (e >> 1) * 16 + 8 * (e & 1)) = sx[it];
+                *reinterpret_cast<uint4*>(Xh + lv * 16 + 8 * (e & 1)) = sx[it];
             }
         }
 #pragma unroll
         for (int it = 0; it < NSG; ++it) {
             const int e = threadIdx.x + NTHR * it;
-            if (e < WG_NV * (CB / 8)) *reinterpret_cast<uint4*>(Gt + (e / (CB / 8)) * CB + 8 * (e % (CB / 8))) = sg[it];
+            const int vv = e / (CB / 8);
+            if (e < WG_NV * (CB / 8)) *reinterpret_cast<uint4*>(Gt + (vv >> 3) * GRS + (vv & 7) * GVS + 8 * (e % (CB / 8))) = sg[it];
         }
     };
 
@@ -1942,8 +1996,8 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void wgrad_k3_bf16_kernel
             bf16x8 bfr[NT];
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
-                const unsigned short* g0 = Gt + (row * 8 + q) * CB + 16 * j + 4 * p;
-                bfr[j] = tr_frag(g0, g0 + 4 * CB);
+                const unsigned short* g0 = Gt + row * GRS + q * GVS + 16 * j + 4 * p;
+                bfr[j] = tr_frag(g0, g0 + 4 * GVS);
                 if (do_bias) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) bsum[j] += (float)bfr[j][e];
@@ -1954,7 +2008,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void wgrad_k3_bf16_kernel
                 if (a < ntaps) {
                     const int t = wave + NW * a;
                     const int dz = t / 9, dy = (t / 3) % 3, dx = t % 3;
-                    const unsigned short* a0 = Xh + (((z + dz) * WG_HY + (y + dy)) * WG_HX + q + dx) * 16 + 4 * p;
+                    const unsigned short* a0 = Xh + (((z + dz) * WG_HY + (y + dy)) * WG_XP + q + dx) * 16 + 4 * p;
                     const bf16x8 afr = tr_frag(a0, a0 + 4 * 16);
 #pragma unroll
                     for (int j = 0; j < NT; ++j) acc[a][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr, bfr[j], acc[a][j], 0, 0, 0);
@@ -2520,8 +2574,14 @@ __global__ __launch_bounds__(256, 2) void wgrad_k2s2_bf16_kernel(const bf16* __r
     constexpr int CB = 16 * NT;
     constexpr int HZ = 2 * WG_TZ, HY = 2 * WG_TY, HX = 2 * WG_TX;     // 8 x 8 x 16 HI voxels
     constexpr int NHI = HZ * HY * HX;                                   // 1024
-    __shared__ __attribute__((aligned(16))) unsigned short Xh[NHI * 16];
-    __shared__ __attribute__((aligned(16))) unsigned short Gt[WG_NV * CB];
+    // bank-conflict-free LDS images for the transposed reads, as in wgrad_k3_bf16_kernel.  HI: a lane group reads voxels 2q (+dx) of
+    // the HI rows 2 kg (+dy) -- 16 q dwords apart, so the rows of kg and kg + 1 must land 8 (mod 16) dwords apart: x-row pitch
+    // 16 voxels + 16 bytes (two rows = 264 dwords = 8 mod 64)
+    constexpr int HXP = HX * 16 + (WG_PAD ? 8 : 0);                     // elements
+    constexpr int GVS = WG_PAD && NT == 4 ? 80 : CB;
+    constexpr int GRS = 8 * GVS + (!WG_PAD ? 0 : NT == 2 ? 16 : 64);
+    __shared__ __attribute__((aligned(16))) unsigned short Xh[HZ * HY * HXP];
+    __shared__ __attribute__((aligned(16))) unsigned short Gt[(WG_NV / 8) * GRS];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int kg = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
     const int ci0 = (blockIdx.x / nCoBlk) * 16;
@@ -2562,7 +2622,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_k2s2_bf16_kernel(const bf16* __r
 #pragma unroll
             for (int it = 0; it < NHI * 2 / 256; ++it) {
                 const int e = threadIdx.x + 256 * it;
-                *reinterpret_cast<uint4*>(Xh + (e >> 1) * 16 + 8 * (e & 1)) = sx[it];
+                const int hv = e >> 1;
+                *reinterpret_cast<uint4*>(Xh + (hv / HX) * HXP + (hv % HX) * 16 + 8 * (e & 1)) = sx[it];
             }
         }
         {   // ---- LO tile: 128 voxels x CB channels
@@ -2581,7 +2642,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_k2s2_bf16_kernel(const bf16* __r
 #pragma unroll
             for (int it = 0; it < NSG; ++it) {
                 const int e = threadIdx.x + 256 * it;
-                if (e < WG_NV * (CB / 8)) *reinterpret_cast<uint4*>(Gt + (e / (CB / 8)) * CB + 8 * (e % (CB / 8))) = sg[it];
+                const int vv = e / (CB / 8);
+                if (e < WG_NV * (CB / 8)) *reinterpret_cast<uint4*>(Gt + (vv >> 3) * GRS + (vv & 7) * GVS + 8 * (e % (CB / 8))) = sg[it];
             }
         }
         __syncthreads();
@@ -2591,8 +2653,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_k2s2_bf16_kernel(const bf16* __r
             bf16x8 bfr[NT];
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
-                const unsigned short* g0 = Gt + (row * 8 + q) * CB + 16 * j + 4 * p;
-                bfr[j] = tr_frag(g0, g0 + 4 * CB);
+                const unsigned short* g0 = Gt + row * GRS + q * GVS + 16 * j + 4 * p;
+                bfr[j] = tr_frag(g0, g0 + 4 * GVS);
                 if (do_bias) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) bsum[j] += (float)bfr[j][e];
@@ -2603,7 +2665,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_k2s2_bf16_kernel(const bf16* __r
                 const int t = 2 * wave + a;
                 const int dz = t >> 2, dy = (t >> 1) & 1, dx = t & 1;
                 // HI voxel of LO voxel (z, y, x = q (+4)) : (2z+dz, 2y+dy, 2x+dx)
-                const unsigned short* a0 = Xh + (((2 * z + dz) * HY + (2 * y + dy)) * HX + 2 * q + dx) * 16 + 4 * p;
+                const unsigned short* a0 = Xh + ((2 * z + dz) * HY + (2 * y + dy)) * HXP + (2 * q + dx) * 16 + 4 * p;
                 const bf16x8 afr = tr_frag(a0, a0 + 8 * 16);
 #pragma unroll
                 for (int j = 0; j < NT; ++j) acc[a][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr, bfr[j], acc[a][j], 0, 0, 0);
@@ -3256,12 +3318,14 @@ extern "C" int dycon_conv_gemm_ex(const void* x, const void* wfrag, const float*
         const bool split = sk.splits > 1 && workspace && ws_bytes >= (size_t)sk.splits * M * N * sizeof(float);
         dim3 grid(cdiv(M, CT_BM), N / CT_BN, split ? sk.splits : 1);
         static const bool tile64 = env_ll("DYCON_TILE_KS64", 1) != 0;
+        static const bool lds_epi = env_ll("DYCON_TILE_LDS_EPI", 1) != 0;
+        const int layout = split && defer_finish ? 1 : lds_epi ? 0 : 2;
         if (tile64 && Cin % 64 == 0 && sk.kc_per_split % 2 == 0)
             conv_k3_tile_kernel<2><<<grid, 256, 0, stream>>>((const bf16*)x, (const bf16*)wfrag, bias, (bf16*)y, split ? workspace : nullptr, B,
-                                                             Di, Hi, Wi, Cin, N, NT, nKC, sk.kc_per_split, accumulate, split && defer_finish);
+                                                             Di, Hi, Wi, Cin, N, NT, nKC, sk.kc_per_split, accumulate, layout);
         else
             conv_k3_tile_kernel<1><<<grid, 256, 0, stream>>>((const bf16*)x, (const bf16*)wfrag, bias, (bf16*)y, split ? workspace : nullptr, B,
-                                                             Di, Hi, Wi, Cin, N, NT, nKC, sk.kc_per_split, accumulate, split && defer_finish);
+                                                             Di, Hi, Wi, Cin, N, NT, nKC, sk.kc_per_split, accumulate, layout);
         DYCON_LAUNCH_CHECK();
         if (split && !defer_finish) {
             long long blocks = (M * N / 4 + 255) / 256;

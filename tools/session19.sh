@@ -1,0 +1,16 @@
+#!/bin/bash
+# LDS-staged slab epilogue of conv_k3_tile_kernel: parity, then A/B (DYCON_TILE_LDS_EPI=0 is the lane-per-element epilogue)
+set -o pipefail
+R=$GRAFT_REPO_ROOT; cd $R
+mkdir -p gpurun_out
+timeout -k 10 900 python -m pytest tests/test_ops_gpu.py tests/test_fullsize_gpu.py -x -q -k "conv" 2>&1 | tail -5 || exit 1
+out=gpurun_out/s19_tile_epilogue.txt
+: > $out
+for i in 1 2; do for e in 0 1; do
+  echo "DYCON_TILE_LDS_EPI=$e" >> $out
+  DYCON_TILE_LDS_EPI=$e timeout -k 10 120 python tools/conv_micro2.py 128 128 12 200 2>&1 | grep -v amdgpu.ids >> $out || exit 1
+  DYCON_TILE_LDS_EPI=$e timeout -k 10 120 python tools/conv_micro2.py 256 256 6 200 2>&1 | grep -v amdgpu.ids >> $out || exit 1
+  DYCON_TILE_LDS_EPI=$e timeout -k 10 120 python tools/conv_micro2.py 128 128 14 200 2>&1 | grep -v amdgpu.ids >> $out || exit 1
+done; done
+for i in 1 2 3; do for e in 0 1; do echo -n "DYCON_TILE_LDS_EPI=$e  " >> $out; DYCON_TILE_LDS_EPI=$e timeout -k 10 200 bash tools/variant_bench.sh dycon_paper_replication_amd/libdycon_hip.so 2>&1 | grep -v amdgpu.ids >> $out || exit 1; done; done
+cat $out
