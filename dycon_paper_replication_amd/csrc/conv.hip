@@ -300,18 +300,14 @@ constexpr int CT_OS = CT_BN + 4;                            // fp32 row stride o
 #ifndef CT_DIAG
 #define CT_DIAG 0     // timing diagnostics only (wrong results): 1 no A loads, 2 no B loads, 4 no slab stores, 8 no MFMAs (bit mask)
 #endif
-// BREG: the B (weight) fragments never touch LDS -- every wave loads the four fragments of its 64 columns straight into registers
-// (the packed layout is already per-lane), three k-steps deep.  Diagnostic builds (profiles/r03_conv_tile_bounds.txt) have the k-loop
-// bound by LDS traffic, two thirds of it the B tile (16 KB published + 32 KB read back per step against 8 KB + 16 KB for A), while
-// the weight loads themselves cost ~1 us of a 21 us launch (L2 / L1 hits: the two waves of a column half load the same lines).
-template <int KS2, bool BREG = false>
-__global__ __launch_bounds__(256, BREG ? 2 : KS2 == 1 ? 4 : 3) void conv_k3_tile_kernel(const bf16* __restrict__ X, const bf16* __restrict__ Wf,
+template <int KS2>
+__global__ __launch_bounds__(256, KS2 == 1 ? 4 : 3) void conv_k3_tile_kernel(const bf16* __restrict__ X, const bf16* __restrict__ Wf,
                                                            const float* __restrict__ bias, bf16* __restrict__ Y,
                                                            float* __restrict__ slab, int B, int D, int H, int W, int Cin, int N,
                                                            int NT, int nKC, int kc_per_split, int accumulate, int span_major = 0) {
     // one LDS block: the double-buffered A / B tiles of the k-loop, re-used by the slab epilogue as a 64 x 128 fp32 image
     constexpr int A_ELEMS = CT_BM * CT_AS, B_ELEMS = 8 * 64 * 8;
-    constexpr int KLOOP_BYTES = 2 * KS2 * (A_ELEMS + (BREG ? 0 : B_ELEMS)) * 2, EPI_BYTES = CT_BM * CT_OS * 4;
+    constexpr int KLOOP_BYTES = 2 * KS2 * (A_ELEMS + B_ELEMS) * 2, EPI_BYTES = CT_BM * CT_OS * 4;
     __shared__ __attribute__((aligned(16))) unsigned char lds_raw[KLOOP_BYTES > EPI_BYTES ? KLOOP_BYTES : EPI_BYTES];
     unsigned short (*As)[KS2][A_ELEMS] = reinterpret_cast<unsigned short (*)[KS2][A_ELEMS]>(lds_raw);
     unsigned short (*Bs)[KS2][B_ELEMS] = reinterpret_cast<unsigned short (*)[KS2][B_ELEMS]>(lds_raw + 2 * KS2 * A_ELEMS * 2);
@@ -348,7 +344,7 @@ __global__ __launch_bounds__(256, BREG ? 2 : KS2 == 1 ? 4 : 3) void conv_k3_tile
     const unsigned boff = threadIdx.x * 16u;
     // Two register stages keep the global loads of two k-steps in flight under the MFMAs of a third (more stages spill at the
     // register budget that lets several workgroups share a CU, which hides the rest of the L2 latency).
-    struct Stage { uint4 a[KS2], b[BREG ? 4 * KS2 : 2 * KS2]; };
+    struct Stage { uint4 a[KS2], b0[KS2], b1[KS2]; };
     auto request = [&](Stage& st) {
         const int tt = min(t, 26);
         const int dz = tt / 9, dy = (tt / 3) % 3, dx = tt % 3;                    // wave-uniform
@@ -360,13 +356,8 @@ __global__ __launch_bounds__(256, BREG ? 2 : KS2 == 1 ? 4 : 3) void conv_k3_tile
             st.a[u] = make_uint4(0, 0, 0, 0);
             if (!(CT_DIAG & 1) && in && kreq + u < kc1) st.a[u] = *reinterpret_cast<const uint4*>(xs + aoff + 64 * u);
             if (!(CT_DIAG & 2) || kreq == kc0) {
-                if constexpr (BREG) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) st.b[4 * u + j] = *reinterpret_cast<const uint4*>(ws + (long long)u * NT * 1024 + ((wn * 4 + j) * 64 + lane) * 16);
-                } else {
-                    st.b[2 * u] = *reinterpret_cast<const uint4*>(ws + (long long)u * NT * 1024 + boff);
-                    st.b[2 * u + 1] = *reinterpret_cast<const uint4*>(ws + (long long)u * NT * 1024 + boff + 4096);
-                }
+                st.b0[u] = *reinterpret_cast<const uint4*>(ws + (long long)u * NT * 1024 + boff);
+                st.b1[u] = *reinterpret_cast<const uint4*>(ws + (long long)u * NT * 1024 + boff + 4096);
             }
         }
         kreq += KS2;
@@ -377,10 +368,8 @@ __global__ __launch_bounds__(256, BREG ? 2 : KS2 == 1 ? 4 : 3) void conv_k3_tile
 #pragma unroll
         for (int u = 0; u < KS2; ++u) {
             *reinterpret_cast<uint4*>(&As[buf][u][arow * CT_AS + 8 * aq]) = st.a[u];
-            if constexpr (!BREG) {
-                *reinterpret_cast<uint4*>(&Bs[buf][u][threadIdx.x * 8]) = st.b[2 * u];
-                *reinterpret_cast<uint4*>(&Bs[buf][u][(threadIdx.x + 256) * 8]) = st.b[2 * u + 1];
-            }
+            *reinterpret_cast<uint4*>(&Bs[buf][u][threadIdx.x * 8]) = st.b0[u];
+            *reinterpret_cast<uint4*>(&Bs[buf][u][(threadIdx.x + 256) * 8]) = st.b1[u];
         }
     };
     f32x4 acc[2][4];
@@ -388,7 +377,7 @@ __global__ __launch_bounds__(256, BREG ? 2 : KS2 == 1 ? 4 : 3) void conv_k3_tile
     for (int m = 0; m < 2; ++m)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[m][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    auto compute = [&](int buf, const Stage& st) {
+    auto compute = [&](int buf) {
 #pragma unroll
         for (int u = 0; u < KS2; ++u) {
             bf16x8 a[2], b[4];
@@ -396,10 +385,8 @@ __global__ __launch_bounds__(256, BREG ? 2 : KS2 == 1 ? 4 : 3) void conv_k3_tile
             for (int m = 0; m < 2; ++m)
                 a[m] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(&As[buf][u][(wm * 32 + m * 16 + r) * CT_AS + 8 * kg]));
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                if constexpr (BREG) b[j] = __builtin_bit_cast(bf16x8, st.b[4 * u + j]);
-                else b[j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(&Bs[buf][u][((wn * 4 + j) * 64 + lane) * 8]));
-            }
+            for (int j = 0; j < 4; ++j)
+                b[j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(&Bs[buf][u][((wn * 4 + j) * 64 + lane) * 8]));
 #pragma unroll
             for (int m = 0; m < 2; ++m)
 #pragma unroll
@@ -410,34 +397,17 @@ __global__ __launch_bounds__(256, BREG ? 2 : KS2 == 1 ? 4 : 3) void conv_k3_tile
         }
     };
 
+    Stage s0, s1;
+    request(s0);
+    publish(s0, 0);                                            // k-step 0
+    request(s1); request(s0);                                  // k-steps 1, 2 in flight (stage of k-step j: j % 2)
+    __syncthreads();
     const int nk = (kc1 - kc0 + KS2 - 1) / KS2;
-    if constexpr (BREG) {
-        // k-step j: A tile in LDS buffer j % 2 (published during step j - 1), B fragments in register stage j % 3; a stage is
-        // re-requested (k-step j + 3) as soon as its MFMAs are issued
-        Stage s0, s1, s2;
-        request(s0); request(s1); request(s2);
-        publish(s0, 0);
-        __syncthreads();
-        for (int j = 0;;) {
-            compute(0, s0); publish(s1, 1); request(s0); __syncthreads(); if (++j >= nk) break;
-            compute(1, s1); publish(s2, 0); request(s1); __syncthreads(); if (++j >= nk) break;
-            compute(0, s2); publish(s0, 1); request(s2); __syncthreads(); if (++j >= nk) break;
-            compute(1, s0); publish(s1, 0); request(s0); __syncthreads(); if (++j >= nk) break;
-            compute(0, s1); publish(s2, 1); request(s1); __syncthreads(); if (++j >= nk) break;
-            compute(1, s2); publish(s0, 0); request(s2); __syncthreads(); if (++j >= nk) break;
-        }
-    } else {
-        Stage s0, s1;
-        request(s0);
-        publish(s0, 0);                                            // k-step 0
-        request(s1); request(s0);                                  // k-steps 1, 2 in flight (stage of k-step j: j % 2)
-        __syncthreads();
-        // iteration j: MFMAs on LDS buffer j % 2; publish k-step j + 1 into the other buffer; request k-step j + 3 into the freed stage
-        for (int j = 0; j < nk; j += 2) {
-            compute(0, s0); publish(s1, 1); request(s1); __syncthreads();
-            if (j + 1 >= nk) break;
-            compute(1, s1); publish(s0, 0); request(s0); __syncthreads();
-        }
+    // iteration j: MFMAs on LDS buffer j % 2; publish k-step j + 1 into the other buffer; request k-step j + 3 into the freed stage
+    for (int j = 0; j < nk; j += 2) {
+        compute(0); publish(s1, 1); request(s1); __syncthreads();
+        if (j + 1 >= nk) break;
+        compute(1); publish(s0, 0); request(s0); __syncthreads();
     }
     // epilogue.  D layout of a 16x16 tile: column = lane & 15, row = 4 * (lane >> 4) + i
     if (slab && span_major == 0) {
@@ -3350,11 +3320,7 @@ extern "C" int dycon_conv_gemm_ex(const void* x, const void* wfrag, const float*
         static const bool tile64 = env_ll("DYCON_TILE_KS64", 1) != 0;
         static const bool lds_epi = env_ll("DYCON_TILE_LDS_EPI", 1) != 0;
         const int layout = split && defer_finish ? 1 : lds_epi ? 0 : 2;
-        static const bool breg = env_ll("DYCON_TILE_BREG", 1) != 0;
-        if (tile64 && breg && Cin % 64 == 0 && sk.kc_per_split % 2 == 0)
-            conv_k3_tile_kernel<2, true><<<grid, 256, 0, stream>>>((const bf16*)x, (const bf16*)wfrag, bias, (bf16*)y, split ? workspace : nullptr, B,
-                                                                   Di, Hi, Wi, Cin, N, NT, nKC, sk.kc_per_split, accumulate, layout);
-        else if (tile64 && Cin % 64 == 0 && sk.kc_per_split % 2 == 0)
+        if (tile64 && Cin % 64 == 0 && sk.kc_per_split % 2 == 0)
             conv_k3_tile_kernel<2><<<grid, 256, 0, stream>>>((const bf16*)x, (const bf16*)wfrag, bias, (bf16*)y, split ? workspace : nullptr, B,
                                                              Di, Hi, Wi, Cin, N, NT, nKC, sk.kc_per_split, accumulate, layout);
         else
