@@ -11,11 +11,15 @@ __device__ __forceinline__ int load_label(const void* labels, int label_bytes, l
     return label_bytes == 8 ? (int)((const long long*)labels)[i] : (int)((const uint8_t*)labels)[i];
 }
 
-// FAST: hardware exp2/log2/rcp sequences (1-2 ulp) instead of the libm routines; the bf16 step uses them (its logits carry bf16
-// noise), the fp32 parity mode does not.  The voxel-loss kernels are bound by these sequences, not by their 60 MB of traffic.
-template <bool FAST> __device__ __forceinline__ float fexp(float x) { return FAST ? __expf(x) : expf(x); }
-template <bool FAST> __device__ __forceinline__ float flog(float x) { return FAST ? __logf(x) : logf(x); }
-template <bool FAST> __device__ __forceinline__ float fdiv(float a, float b) { return FAST ? __fdividef(a, b) : a / b; }
+// FAST: the bare hardware v_exp_f32 / v_log_f32 / v_rcp_f32 (1 ulp) instead of the libm routines; the bf16 step uses them (its logits
+// carry bf16 noise), the fp32 parity mode does not.  The voxel-loss kernels and the FeCL pair epilogue are bound by these sequences,
+// not by their traffic.  (Until round 3 FAST meant __expf / __logf / __fdividef / __frcp_rn, which the compiler expands with
+// denormal-range scaling -- v_ldexp, v_cmp_class, v_cndmask around every v_exp / v_log -- and, for the divisions, the full IEEE
+// sequence: ten instructions where one v_rcp_f32 does.)  Arguments outside the normal range only occur where the result is immaterial:
+// exp of a logit difference below -87 flushes to 0 instead of a denormal; every log / rcp argument here is >= 1e-18.
+template <bool FAST> __device__ __forceinline__ float fexp(float x) { return FAST ? __builtin_amdgcn_exp2f(x * 1.4426950408889634f) : expf(x); }
+template <bool FAST> __device__ __forceinline__ float flog(float x) { return FAST ? __builtin_amdgcn_logf(x) * 0.6931471805599453f : logf(x); }
+template <bool FAST> __device__ __forceinline__ float fdiv(float a, float b) { return FAST ? a * __builtin_amdgcn_rcpf(b) : a / b; }
 
 struct Soft2 { float p0, p1, lse, m; };
 template <bool FAST> __device__ __forceinline__ Soft2 softmax2(float l0, float l1) {
@@ -276,7 +280,8 @@ template <> struct FeclTile<float> {
 };
 template <> struct FeclTile<bf16> {
     typedef unsigned short E;
-    static constexpr int KS = 32, PAD = 8, TPAD = 8;
+    static constexpr int KS = 32, PAD = 16, TPAD = 8;   // row stride = 2 (mod 16) 16-byte slots: every ds_read_b128 lane group of a Gram fragment
+                                                        // (rows r, slot offset kg) hits 16 distinct slots; PAD = 8 had 41 % of the LDS cycles as conflicts
 };
 
 __device__ __forceinline__ void stage_rows(float* __restrict__ dst, int stride, int Dp, const float* __restrict__ src, int row0,
@@ -291,7 +296,15 @@ __device__ __forceinline__ void stage_rows(float* __restrict__ dst, int stride, 
 __device__ __forceinline__ void stage_rows(unsigned short* __restrict__ dst, int stride, int Dp, const bf16* __restrict__ src,
                                            int row0, int N, int Dm) {
     const unsigned short* s16 = reinterpret_cast<const unsigned short*>(src);
-    if ((Dm & 7) == 0) {   // 16-byte pieces
+    if ((Dm & 7) == 0 && 256 % (Dp >> 3) == 0) {   // 16-byte pieces, a thread's column fixed: no division per piece (see fecl_kernel)
+        const int ppr = Dp >> 3, rstep = 256 / ppr;
+        const int rr0 = threadIdx.x / ppr, k = (threadIdx.x - rr0 * ppr) << 3;
+        for (int r = rr0; r < FT; r += rstep) {
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (row0 + r < N && k < Dm) v = *reinterpret_cast<const uint4*>(s16 + (long long)(row0 + r) * Dm + k);
+            *reinterpret_cast<uint4*>(dst + r * stride + k) = v;
+        }
+    } else if ((Dm & 7) == 0) {   // 16-byte pieces
         const int ppr = Dp >> 3;
         for (int e = threadIdx.x; e < FT * ppr; e += 256) {
             const int r = e / ppr, k = (e - r * ppr) << 3;
@@ -391,8 +404,9 @@ __device__ __forceinline__ float row16_max(float v) {
     return v;
 }
 
-// fp32 storage (parity mode): IEEE expf/logf/division.  bf16 storage: hardware v_exp/v_log/v_rcp forms (1e-6 relative,
-// far below the bf16 rounding of the operands) -- the pair epilogue is the VALU-bound part of FeCL.
+// fp32 storage (parity mode): IEEE expf/logf/division.  bf16 storage: fexp / flog / fdiv<true> (hardware forms, see the top of this file);
+// every argument of the pair epilogue is in the normal range: exponents L - m in [-2/tau, 0], denominators a + n >= exp(-2/tau),
+// 1 - s + 1e-18 >= 1e-18.
 
 // d/dP of phi(P) = -log(P+eps) * (1-P)^gamma   (gamma = 0 <=> no focal weight)
 template <bool FAST>
@@ -414,10 +428,10 @@ __device__ __forceinline__ void focal_terms(float P, float gamma, int focal, flo
 // so one exp, one rcp and one log per direction replace one exp, one log and four divisions (the 1e-18 guards of the reference
 // formula only matter for d < 1e-15, which a + n never is: n counts at least exp(-2/tau) per other-class column).
 __device__ __forceinline__ void fast_pair(float lm /* L - m */, float n, float& a, float& r, float& lgP, float& adphi) {
-    a = __expf(lm);
+    a = fexp<true>(lm);
     const float d = a + n;
-    r = __frcp_rn(d);
-    lgP = lm - __logf(d);
+    r = __builtin_amdgcn_rcpf(d);
+    lgP = lm - flog<true>(d);
     adphi = n * r * (2.f * a * lgP - n);
 }
 
@@ -503,9 +517,25 @@ __global__ __launch_bounds__(256) void fecl_kernel(const T* __restrict__ F, cons
     // (not in the gradient pass: its 64 accumulator registers plus a staged tile leave room for one wave per SIMD only -- measured slower)
     const bool pref = (PASS != 4 || FECL_P4_PREF) && sizeof(T) == 2 && (Dm & 7) == 0 && Dp <= 256;
     uint4 pfr[NPF];
+    // A thread's piece of a staged tile: with 256 % (pieces per row) == 0 (Dp = 32 .. 256 in powers of two) its column never changes
+    // and its row advances by a fixed step, so nothing is divided per piece -- the e / ppr form below cost ~25 vector instructions per
+    // piece, 16 pieces per tile: 400 of the 468 VALU instructions per tile and wave that PMC counted in pass 1
+    // (profiles/r03_fecl_pmc.txt), with the vector ALU the busiest pipe of passes 1 and 2.
+    const int ppr_ = Dp >> 3;
+    const bool lin = 256 % ppr_ == 0;
+    const int rstep = lin ? 256 / ppr_ : 0, rr0 = threadIdx.x / ppr_, k0 = (threadIdx.x - rr0 * ppr_) << 3;
     auto prefetch = [&](const T* src, int row0) {
         const unsigned short* s16 = reinterpret_cast<const unsigned short*>(src);
         const int ppr = Dp >> 3;
+        if (lin) {
+#pragma unroll
+            for (int it = 0; it < NPF; ++it) {
+                const int rr = rr0 + it * rstep;
+                pfr[it] = make_uint4(0, 0, 0, 0);
+                if (rr < FT && row0 + rr < N && k0 < Dm) pfr[it] = *reinterpret_cast<const uint4*>(s16 + (long long)(row0 + rr) * Dm + k0);
+            }
+            return;
+        }
 #pragma unroll
         for (int it = 0; it < NPF; ++it) {
             const int e = threadIdx.x + 256 * it;
@@ -516,6 +546,14 @@ __global__ __launch_bounds__(256) void fecl_kernel(const T* __restrict__ F, cons
     };
     auto commit = [&]() {
         const int ppr = Dp >> 3;
+        if (lin) {
+#pragma unroll
+            for (int it = 0; it < NPF; ++it) {
+                const int rr = rr0 + it * rstep;
+                if (rr < FT) *reinterpret_cast<uint4*>(reinterpret_cast<unsigned short*>(Fj) + rr * stride + k0) = pfr[it];
+            }
+            return;
+        }
 #pragma unroll
         for (int it = 0; it < NPF; ++it) {
             const int e = threadIdx.x + 256 * it;
@@ -571,7 +609,7 @@ __global__ __launch_bounds__(256) void fecl_kernel(const T* __restrict__ F, cons
                 const int gj = j0 + 16 * j + r;
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
-                    if (gj < N && gj != gi[i]) a0[i] = fmaxf(a0[i], fdiv<FAST>(acc[j][i], tau));
+                    if (gj < N && gj != gi[i]) a0[i] = fmaxf(a0[i], FAST ? acc[j][i] * inv_tau : acc[j][i] / tau);
             }
         } else if (PASS == 2) {
 #pragma unroll
@@ -582,7 +620,7 @@ __global__ __launch_bounds__(256) void fecl_kernel(const T* __restrict__ F, cons
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     if (mk == mrow[i]) a1[i] += 1.f;
-                    else a0[i] += FAST ? __expf(acc[j][i] * inv_tau - mj) : expf(acc[j][i] / tau - mj);
+                    else a0[i] += FAST ? fexp<true>(acc[j][i] * inv_tau - mj) : expf(acc[j][i] / tau - mj);
                 }
             }
         } else if (PASS == 3) {
@@ -632,7 +670,7 @@ __global__ __launch_bounds__(256) void fecl_kernel(const T* __restrict__ F, cons
                             fast_pair(l - mi[i], nj, a, rr, lgP, adphi);
                             tv += kj * nj * rr * rr * adphi;
                         } else {
-                            tv = __expf(l - mj) * hrow[i] + __expf(l - mi[i]) * hj;
+                            tv = fexp<true>(l - mj) * hrow[i] + fexp<true>(l - mi[i]) * hj;
                         }
                         tv *= stud_scale * inv_tau;
                     } else if (vj && vi[i] && gj != gi[i]) {
