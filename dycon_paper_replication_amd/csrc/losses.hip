@@ -774,6 +774,193 @@ __global__ __launch_bounds__(256) void fecl_kernel(const T* __restrict__ F, cons
     }
 }
 
+// =================================================================================================
+// FeCL passes 1-3 at large N (bf16 storage; focal gamma = 2, or no focal weight): 128-row blocks on v_mfma_f32_32x32x16_bf16.
+//
+// fecl_kernel above gives a workgroup 64 rows and re-reads, per 64-column tile, both operands from LDS (160 KB of ds_read_b128 per
+// tile for 64 x 64 pairs), stages the column tile between TWO barriers and fetches it once per 64 rows: at N = 15 680 its passes run
+// at 13-18 % of the matrix pipe with the waves waiting (barriers, LDS) half their life (profiles/r03_fecl_n15680.txt).  Here
+//   * a workgroup owns 128 rows, a wave 32 of them; the wave's row fragments (B operand: 32 rows x Dm, 64 registers) are loaded
+//     from global memory ONCE and stay in registers for all column tiles;
+//   * the column tile is the A operand (32 columns x 16 k per instruction, one ds_read_b128 each), so the product comes out
+//     transposed: a lane holds ONE row i (its B column) against 32 columns j of the tile, the row's state and accumulators are
+//     scalars per lane, and the per-column statistics are 16-byte LDS broadcasts;
+//   * column tiles are double-buffered in LDS: one barrier per tile, the next tile's global loads in registers meanwhile;
+//   * 64 KB of LDS reads per tile and wave for 32 x 64 pairs (2.5 x fewer per pair), a tile fetched once per 128 rows.
+// Same arithmetic per pair as fecl_kernel<bf16> (fast_pair / hardware exp, log, rcp), same workspace layout: the gradient pass
+// (fecl_kernel<bf16, 4>) consumes what these passes leave.  Row sums are accumulated in a different order than fecl_kernel's
+// (fp32, ~1e-7 relative).
+// =================================================================================================
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int F2_ROWS = 128;   // rows per workgroup (4 waves x 32)
+constexpr int F2_PAD = 8;      // column-tile row stride Dm + 8 elements = odd number of 16-byte slots: the 32 rows of an A-fragment read
+                               // (lanes 0-31 slot 2q, lanes 32-63 slot 2q + 1) fall in 16 distinct slots per ds_read_b128 lane group
+
+template <int PASS, int NQ>     // NQ = Dm / 16 k-steps (compile time: a predicated k-loop made the compiler copy the 32 accumulators per step)
+__global__ __launch_bounds__(256, 2) void fecl_rows128_kernel(const bf16* __restrict__ F, const bf16* __restrict__ Tch,
+                                                              const float* __restrict__ mask, const float* __restrict__ gamb, int N,
+                                                              int Dm, float tau, int focal, float thr, float* __restrict__ ws,
+                                                              double* __restrict__ out, int Btot, int CS, int tiles_per_split) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    const int stride = Dm + F2_PAD, tile_elems = FT * stride;
+    unsigned short* Fj = reinterpret_cast<unsigned short*>(lds_raw);                       // [2][64][stride]
+    float* cst = reinterpret_cast<float*>(lds_raw + ((size_t)2 * tile_elems * 2 + 15) / 16 * 16);   // [2][{max, mask}][64]
+    const int b = blockIdx.y, cs = blockIdx.z, i0 = blockIdx.x * F2_ROWS;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, rl = lane & 31, half = lane >> 5;
+    const long long BN = (long long)Btot * N, rb = (long long)b * N;
+    float* wm = ws;
+    float* wn = ws + (long long)CS * BN;
+    float* wc = ws + 2LL * CS * BN;
+    float* wh = ws + 3LL * CS * BN;
+    float* wk = ws + 4LL * CS * BN;
+    auto ld_max = [&](const float* base, long long idx) { float v = base[idx]; for (int z = 1; z < CS; ++z) v = fmaxf(v, base[z * BN + idx]); return v; };
+    auto ld_sum = [&](const float* base, long long idx) { float v = base[idx]; for (int z = 1; z < CS; ++z) v += base[z * BN + idx]; return v; };
+    const unsigned short* Fb = reinterpret_cast<const unsigned short*>(F) + (long long)b * N * Dm;
+    const unsigned short* Tb = Tch ? reinterpret_cast<const unsigned short*>(Tch) + (long long)b * N * Dm : nullptr;
+    const float* mb = mask + rb;
+
+    // this lane's row: fragments (k = 16 q + 8 half .. + 7) resident for the whole kernel
+    const int gi = i0 + 32 * wave + rl;
+    const bool vi = gi < N;
+    uint4 bfrag[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        bfrag[q] = make_uint4(0, 0, 0, 0);
+        if (vi) bfrag[q] = *reinterpret_cast<const uint4*>(Fb + (long long)gi * Dm + 16 * q + 8 * half);
+    }
+    const float mrow = vi ? mb[gi] : -1.f;
+    float nrow = 0.f;
+    if (PASS >= 3 && vi) nrow = ld_sum(wn, rb + gi);
+    float a0 = 0.f, a1 = 0.f, hrow = 0.f, cnum = 0.f, ccnt = 0.f;
+    const float inv_tau = 1.f / tau;
+
+    // staging: a thread owns one 16-byte column of the tile and every rstep-th row (256 % (Dm / 8) == 0: checked on the host)
+    const int ppr = Dm >> 3, rstep = 256 / ppr, rr0 = threadIdx.x / ppr, k0 = (threadIdx.x - rr0 * ppr) << 3;
+    constexpr int NPF = 8;
+    uint4 pfr[NPF];
+    float pst[2] = {0.f, -2.f};
+    const bool cross = PASS == 3 && Tb != nullptr;
+    const int j_beg = cs * tiles_per_split * FT, j_end = min(N, (cs + 1) * tiles_per_split * FT);
+    const int ntile = j_end > j_beg ? (j_end - j_beg + FT - 1) / FT : 0;
+    const int nst = cross ? 2 * ntile : ntile;                 // staged tiles: F_0 (, T_0), F_1 (, T_1), ...
+    auto col0 = [&](int s_) { return j_beg + (cross ? s_ >> 1 : s_) * FT; };
+    auto prefetch = [&](int s_) {
+        const unsigned short* src = cross && (s_ & 1) ? Tb : Fb;
+        const int row0 = col0(s_);
+#pragma unroll
+        for (int it = 0; it < NPF; ++it) {
+            const int rr = rr0 + it * rstep;
+            pfr[it] = make_uint4(0, 0, 0, 0);
+            if (rr < FT && row0 + rr < N) pfr[it] = *reinterpret_cast<const uint4*>(src + (long long)(row0 + rr) * Dm + k0);
+        }
+        if (threadIdx.x < FT) {
+            const int gc = row0 + threadIdx.x;
+            pst[0] = PASS >= 2 && gc < N ? ld_max(wm, rb + gc) : 0.f;
+            pst[1] = gc < N ? mb[gc] : -2.f;
+        }
+    };
+    auto commit = [&](int buf) {
+        unsigned short* dst = Fj + buf * tile_elems;
+#pragma unroll
+        for (int it = 0; it < NPF; ++it) {
+            const int rr = rr0 + it * rstep;
+            if (rr < FT) *reinterpret_cast<uint4*>(dst + rr * stride + k0) = pfr[it];
+        }
+        if (threadIdx.x < FT) { cst[buf * 2 * FT + threadIdx.x] = pst[0]; cst[buf * 2 * FT + FT + threadIdx.x] = pst[1]; }
+    };
+
+    if (nst > 0) { prefetch(0); commit(0); }
+    if (nst > 1) prefetch(1);
+    __syncthreads();
+    for (int s_ = 0; s_ < nst; ++s_) {
+        const int buf = s_ & 1, j0 = col0(s_);
+        const unsigned short* At = Fj + buf * tile_elems + rl * stride + 8 * half;
+        f32x16 acc[2];
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[jt][e] = 0.f;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+#pragma unroll
+            for (int jt = 0; jt < 2; ++jt) {
+                const bf16x8_t a = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(At + jt * 32 * stride + 16 * q));
+                acc[jt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, __builtin_bit_cast(bf16x8_t, bfrag[q]), acc[jt], 0, 0, 0);
+            }
+        }
+        // D[m = column of the tile][n = this lane's row]: register 4 g + e of acc[jt] is column jt*32 + 8 g + 4 half + e
+        const float* cmx = cst + buf * 2 * FT;
+        const bool teacher_tile = cross && (s_ & 1);
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int jl = jt * 32 + 8 * g + 4 * half;
+                const float4 m4 = *reinterpret_cast<const float4*>(cmx + jl);
+                const float4 k4 = *reinterpret_cast<const float4*>(cmx + FT + jl);
+                const float mj4[4] = {m4.x, m4.y, m4.z, m4.w}, mk4[4] = {k4.x, k4.y, k4.z, k4.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int gj = j0 + jl + e;
+                    const float v = acc[jt][4 * g + e];
+                    if (gj >= N) continue;
+                    if (PASS == 1) {
+                        if (gj != gi) a0 = fmaxf(a0, v * inv_tau);
+                    } else if (PASS == 2) {
+                        if (mk4[e] == mrow) a1 += 1.f;
+                        else a0 += fexp<true>(v * inv_tau - mj4[e]);
+                    } else if (!teacher_tile) {
+                        if (mk4[e] == mrow) {
+                            a1 += 1.f;
+                            if (gj != gi) {
+                                float a, rr, lgP, adphi;
+                                fast_pair(v * inv_tau - mj4[e], nrow, a, rr, lgP, adphi);
+                                if (focal) {
+                                    const float om = nrow * rr;
+                                    a0 += -lgP * om * om;             // phi
+                                    hrow -= adphi * rr * rr;          // dphi * (-a / d^2)
+                                } else {
+                                    a0 += -lgP;                       // phi = -log P, dphi * (-a / d^2) = 1 / d
+                                    hrow += rr;
+                                }
+                            }
+                        }
+                    } else {
+                        if (vi && mk4[e] != mrow && v > thr) { cnum += -flog<true>(1.f - v + 1e-18f); ccnt += 1.f; }
+                    }
+                }
+            }
+        if (s_ + 1 < nst) commit(buf ^ 1);
+        if (s_ + 2 < nst) prefetch(s_ + 2);
+        __syncthreads();
+    }
+
+    // the two halves of a wave hold the same 32 rows against different columns
+    if (PASS == 1) {
+        const float v = fmaxf(a0, __shfl_xor(a0, 32, 64));
+        if (half == 0 && vi) wm[cs * BN + rb + gi] = v;
+    } else if (PASS == 2) {
+        const float ns = a0 + __shfl_xor(a0, 32, 64), cn = a1 + __shfl_xor(a1, 32, 64);
+        if (half == 0 && vi) { wn[cs * BN + rb + gi] = ns; wc[cs * BN + rb + gi] = cn; }
+    } else {
+        const float ph = a0 + __shfl_xor(a0, 32, 64), hs = hrow + __shfl_xor(hrow, 32, 64);
+        float lsum = 0.f;
+        if (half == 0 && vi) {
+            const float u = gamb ? gamb[rb + gi] : 1.f;
+            const float kap = u / (ld_sum(wc, rb + gi) - 1.f + 1e-18f);   // total same-class count from pass 2
+            if (cs == 0) wk[rb + gi] = kap;
+            wh[cs * BN + rb + gi] = kap * hs;
+            lsum = ph * kap;
+        }
+        float* red = reinterpret_cast<float*>(lds_raw);   // the tile buffers are dead (the loop ends on a barrier)
+        const float bs = block_sum(lsum, red), bn = block_sum(cnum, red), bc = block_sum(ccnt, red);
+        if (threadIdx.x == 0) {
+            atomicAdd(&out[0], (double)bs);
+            if (Tb) { atomicAdd(&out[1], (double)bn); atomicAdd(&out[2], (double)bc); }
+        }
+    }
+}
+
 // g_feat = sum over the column-split slabs (ordered)
 template <typename T>
 __global__ void fecl_combine_kernel(const float* __restrict__ GS, int CS, long long n, T* __restrict__ GF) {
@@ -929,6 +1116,36 @@ static int fecl_launch(const void* feat, const void* teacher, const float* mask,
     return DYCON_OK;
 }
 
+// passes 1-3 on the 128-row kernel: bf16, a feature dim whose rows split into equal 16-byte columns per thread, the focal weight the
+// reference runs (gamma = 2) or none, and N large enough that one round of 128-row blocks fills the chip
+static bool fecl_rows128_ok(int dtype, int B, int N, int Dm, float gamma, int focal) {
+    static const long long min_n = [] { const char* v = getenv("DYCON_FECL_ROWS128_MIN_N"); return v && *v ? atoll(v) : 8192LL; }();
+    return dtype == DYCON_BF16 && (Dm == 64 || Dm == 128 || Dm == 256) && (!focal || gamma == 2.f) && N >= min_n;
+}
+template <int PASS, int NQ>
+static int fecl_rows128_launch_nq(const void* feat, const void* teacher, const float* mask, const float* gamb, int B, int N, int Dm,
+                                  float tau, int focal, float thr, float* ws, double* out, dycon_stream_t stream) {
+    const size_t lds = ((size_t)2 * FT * (Dm + F2_PAD) * 2 + 15) / 16 * 16 + 2 * 2 * FT * sizeof(float);
+    if (hipFuncSetAttribute((const void*)fecl_rows128_kernel<PASS, NQ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+        dycon_set_error("fecl: cannot reserve %zu bytes of LDS", lds);
+        return DYCON_ERR_LAUNCH;
+    }
+    int CS, tps;
+    fecl_split(B, N, CS, tps);
+    dim3 grid(cdiv(N, F2_ROWS), B, CS);
+    fecl_rows128_kernel<PASS, NQ><<<grid, 256, lds, stream>>>((const bf16*)feat, (const bf16*)teacher, mask, gamb, N, Dm, tau, focal, thr, ws,
+                                                              out, B, CS, tps);
+    DYCON_LAUNCH_CHECK();
+    return DYCON_OK;
+}
+template <int PASS>
+static int fecl_rows128_launch(const void* feat, const void* teacher, const float* mask, const float* gamb, int B, int N, int Dm,
+                               float tau, int focal, float thr, float* ws, double* out, dycon_stream_t stream) {
+    if (Dm == 256) return fecl_rows128_launch_nq<PASS, 16>(feat, teacher, mask, gamb, B, N, Dm, tau, focal, thr, ws, out, stream);
+    if (Dm == 128) return fecl_rows128_launch_nq<PASS, 8>(feat, teacher, mask, gamb, B, N, Dm, tau, focal, thr, ws, out, stream);
+    return fecl_rows128_launch_nq<PASS, 4>(feat, teacher, mask, gamb, B, N, Dm, tau, focal, thr, ws, out, stream);
+}
+
 static int fecl_check(const char* who, const void* feat, const float* mask, int B, int N, int Dm, float tau, size_t ws_bytes) {
     DYCON_REQUIRE(feat && mask && B > 0 && N > 0 && Dm > 0 && tau > 0.f, "%s: bad arguments", who);
     DYCON_REQUIRE(Dm <= 256, "%s: feature dim %d > 256 not supported", who, Dm);
@@ -946,6 +1163,11 @@ extern "C" int dycon_fecl_fwd(const void* feat, const void* teacher, const float
     const int focal = use_focal && !gambling;   // the gambling branch overrides the focal result (dycon_losses.py:209-211)
     if (hipMemsetAsync(out, 0, 4 * sizeof(double), stream) != hipSuccess) { dycon_set_error("fecl_fwd: memset failed"); return DYCON_ERR_LAUNCH; }
     int e = DYCON_OK;
+    if (fecl_rows128_ok(dtype, B, N, Dm, gamma, focal)) {
+        e = fecl_rows128_launch<1>(feat, nullptr, mask, gambling, B, N, Dm, temperature, focal, cross_thresh, workspace, out, stream);
+        if (!e) e = fecl_rows128_launch<2>(feat, nullptr, mask, gambling, B, N, Dm, temperature, focal, cross_thresh, workspace, out, stream);
+        if (!e) e = fecl_rows128_launch<3>(feat, teacher, mask, gambling, B, N, Dm, temperature, focal, cross_thresh, workspace, out, stream);
+    } else
     DYCON_DISPATCH(dtype, {
         e = fecl_launch<T, 1>(feat, nullptr, mask, gambling, B, N, Dm, temperature, gamma, focal, cross_thresh, workspace, out, nullptr, lambda_cross, stream);
         if (!e) e = fecl_launch<T, 2>(feat, nullptr, mask, gambling, B, N, Dm, temperature, gamma, focal, cross_thresh, workspace, out, nullptr, lambda_cross, stream);

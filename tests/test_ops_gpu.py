@@ -458,6 +458,29 @@ def test_fecl_isles_size_vs_rowblock_oracle():
     close(l16[0], ref16, 5e-4, 1e-6)
 
 
+@pytest.mark.parametrize("Dm,focal,use_t,use_g", [(256, True, True, False), (64, False, True, True), (128, True, False, False)])
+def test_fecl_rows128_kernel_vs_oracle(Dm, focal, use_t, use_g):
+    """N >= 8192 in bf16 storage takes passes 1-3 on fecl_rows128_kernel (128-row blocks, 32x32x16 MFMA, row fragments in registers)
+    and the gradient pass on fecl_kernel<bf16, 4> reading what they left: loss and gradient against the fp32 oracle on the rounded
+    inputs, at an N that is a multiple of neither 64 nor 128 (ragged last row block, column tile and column split)."""
+    torch.manual_seed(11)
+    B, N = 2, 8200
+    f = F.normalize(torch.randn(B, N, Dm), dim=-1).bfloat16()
+    t = F.normalize(f.float() + 0.05 * torch.randn(B, N, Dm), dim=-1).bfloat16()
+    mask = (torch.rand(B, N) > 0.85).float()
+    gamb = torch.rand(B, N) if use_g else None
+    epoch = 300
+    thr = OL.threshold_rampup(epoch, 1500, 0.3, 0.5)
+    fr = f.float().requires_grad_(True)
+    ref = OL.fecl(fr, mask.view(B, 1, N), t.float() if use_t else None, gamb.view(B, N) if use_g else None, epoch, 0.6, 2.0, focal, 1500, 1.0)
+    (gr,) = torch.autograd.grad(ref, fr)
+    args = (f.to(DEV), t.to(DEV) if use_t else None, mask.to(DEV), gamb.to(DEV) if use_g else None, 0.6, 2.0, focal, thr, 1.0)
+    loss, st = ops.fecl_fwd(*args)
+    close(loss[0], ref, 3e-4, 1e-6)
+    gf = ops.fecl_bwd(*args, st, torch.ones(1, device=DEV))
+    relclose(gf, gr, 2e-2, "fecl rows128 grad")
+
+
 @pytest.mark.parametrize("norm", ["groupnorm", "none", "instancenorm", "batchnorm"])
 def test_vnet_convblock_reference_fixtures(norm):
     """VNet.ConvBlock(2, 16, co, normalization=...) of the REFERENCE (VNet.py:5-31; fixture vnet_layers.npz, all four
