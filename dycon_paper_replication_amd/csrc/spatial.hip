@@ -103,6 +103,27 @@ __device__ __forceinline__ void tri_src(int o, int in, int out, int align, int& 
     lam = fminf(fmaxf(src - (float)i0, 0.f), 1.f);
 }
 
+// element index -> (channel group, x, y, z, b).  32-bit arithmetic whenever the index fits (every shape of the step): a 64-bit
+// division by a runtime divisor is ~60 vector instructions, five of them per element were most of what these kernels executed
+// (tools/isa_loop_mix.py: 115 division-sequence instructions of 670 in the loop of trilinear_fwd_kernel).
+__device__ __forceinline__ void decode5(long long i, int CG, int W, int H, int D, int& cg, int& x, int& y, int& z, int& b) {
+    if (i < (1ll << 31)) {
+        unsigned q = (unsigned)i;
+        unsigned t = q / (unsigned)CG; cg = (int)(q - t * CG); q = t;
+        t = q / (unsigned)W; x = (int)(q - t * W); q = t;
+        t = q / (unsigned)H; y = (int)(q - t * H); q = t;
+        t = q / (unsigned)D; z = (int)(q - t * D);
+        b = (int)t;
+    } else {
+        cg = (int)(i % CG);
+        long long q = i / CG;
+        x = (int)(q % W); q /= W;
+        y = (int)(q % H); q /= H;
+        z = (int)(q % D);
+        b = (int)(q / D);
+    }
+}
+
 // one thread = one output voxel x VN channels: coordinates once, 8 x 16-byte taps
 template <typename T>
 __global__ void trilinear_fwd_kernel(const T* __restrict__ X, T* __restrict__ Y, int B, int Di, int Hi, int Wi, int Do, int Ho,
@@ -110,18 +131,15 @@ __global__ void trilinear_fwd_kernel(const T* __restrict__ X, T* __restrict__ Y,
     constexpr int VN = Vec16<T>::N;
     const int CG = C / VN;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-        const int cg = (int)(i % CG);
-        long long q = i / CG;
-        const int x = (int)(q % Wo); q /= Wo;
-        const int y = (int)(q % Ho); q /= Ho;
-        const int z = (int)(q % Do);
-        const int b = (int)(q / Do);
+        int cg, x, y, z, b;
+        decode5(i, CG, Wo, Ho, Do, cg, x, y, z, b);
         int z0, z1, y0, y1, x0, x1;
         float lz, ly, lx;
         tri_src(z, Di, Do, align, z0, z1, lz);
         tri_src(y, Hi, Ho, align, y0, y1, ly);
         tri_src(x, Wi, Wo, align, x0, x1, lx);
-        auto at = [&](int zz, int yy, int xx) { return ld16(X + ((((long long)b * Di + zz) * Hi + yy) * Wi + xx) * C + cg * VN); };
+        const T* xb = X + (long long)b * Di * Hi * Wi * C + cg * VN;
+        auto at = [&](int zz, int yy, int xx) { return ld16(xb + (long long)((zz * Hi + yy) * Wi + xx) * C); };
         const Vec16<T> a000 = at(z0, y0, x0), a001 = at(z0, y0, x1), a010 = at(z0, y1, x0), a011 = at(z0, y1, x1);
         const Vec16<T> a100 = at(z1, y0, x0), a101 = at(z1, y0, x1), a110 = at(z1, y1, x0), a111 = at(z1, y1, x1);
         const float w0z = 1.f - lz, w0y = 1.f - ly, w0x = 1.f - lx;
@@ -143,11 +161,19 @@ __device__ __forceinline__ float tri_w(int o, int i, int in, int out, int align)
     return (i == i0 ? 1.f - lam : 0.f) + (i == i1 ? lam : 0.f);
 }
 __device__ __forceinline__ void tri_range(int i, int in, int out, int align, int& lo, int& hi) {
-    // conservative range of outputs whose two taps can include input i (weights outside are exactly 0)
-    const float r = (align && in > 1) ? (float)(out - 1) / (float)(in - 1) : (float)out / (float)in;
-    const int mg = (int)ceilf(0.5f * r) + 1;
-    lo = (int)floorf(((float)i - 1.f) * r) - mg;
-    hi = (int)ceilf(((float)i + 1.f) * r) + mg;
+    // superset of the outputs whose two taps can include input i (weights outside are exactly 0): an output o reads inputs
+    // floor(src(o)) and floor(src(o)) + 1, so it can touch i only if src(o) lies in (i - 1, i + 1).  align: src = o (in-1)/(out-1);
+    // otherwise src = (o + 0.5) in/out - 0.5 (clamped at 0, which only adds outputs to i = 0).  One extra output on either side
+    // absorbs the rounding of the bounds: 6 candidates per axis at scale 2 (4 contribute), where the old +-(r/2 + 1) margin gave 9.
+    if (align && in > 1) {
+        const float r = (float)(out - 1) / (float)(in - 1);
+        lo = (int)floorf(((float)i - 1.f) * r) - 1;
+        hi = (int)ceilf(((float)i + 1.f) * r) + 1;
+    } else {
+        const float r = (float)out / (float)in;
+        lo = (int)floorf(((float)i - 0.5f) * r - 0.5f) - 1;
+        hi = (int)ceilf(((float)i + 1.5f) * r - 0.5f) + 1;
+    }
     if (lo < 0) lo = 0;
     if (hi > out - 1) hi = out - 1;
 }
@@ -158,15 +184,11 @@ template <typename T>
 __global__ void trilinear_bwd_kernel(const T* __restrict__ GY, T* __restrict__ GX, int B, int Di, int Hi, int Wi, int Do, int Ho,
                                      int Wo, int C, int ldy, int coff, int align, long long total) {
     constexpr int VN = Vec16<T>::N;
-    constexpr int MAXO = 18;                       // candidate outputs per axis held in registers (tri_range: 9 at scale 2, 18 at 4.5)
+    constexpr int MAXO = 12;                       // candidate outputs per axis held in registers (tri_range: 6 at scale 2, 12 at 4.5)
     const int CG = C / VN;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-        const int cg = (int)(i % CG);
-        long long q = i / CG;
-        const int x = (int)(q % Wi); q /= Wi;
-        const int y = (int)(q % Hi); q /= Hi;
-        const int z = (int)(q % Di);
-        const int b = (int)(q / Di);
+        int cg, x, y, z, b;
+        decode5(i, CG, Wi, Hi, Di, cg, x, y, z, b);
         int zl, zh, yl, yh, xl, xh;
         tri_range(z, Di, Do, align, zl, zh);
         tri_range(y, Hi, Ho, align, yl, yh);
@@ -180,14 +202,20 @@ __global__ void trilinear_bwd_kernel(const T* __restrict__ GY, T* __restrict__ G
         const bool xfit = xh - xl < MAXO;
 #pragma unroll
         for (int k = 0; k < MAXO; ++k) wxs[k] = (xfit && xl + k <= xh) ? tri_w(xl + k, x, Wi, Wo, align) : 0.f;
-        for (int oz = zl; oz <= zh; ++oz) {
-            const float wz = tri_w(oz, z, Di, Do, align);
-            if (wz == 0.f) continue;
-            for (int oy = yl; oy <= yh; ++oy) {
-                const float wzy = wz * tri_w(oy, y, Hi, Ho, align);
-                if (wzy == 0.f) continue;
-                const T* row = GY + ((((long long)b * Do + oz) * Ho + oy) * Wo + xl) * ldy + coff + cg * VN;
-                if (xfit) {
+        float wys[MAXO];                               // ... and the y-axis weights (they were re-evaluated for every oz)
+        const bool yfit = yh - yl < MAXO;
+#pragma unroll
+        for (int k = 0; k < MAXO; ++k) wys[k] = (yfit && yl + k <= yh) ? tri_w(yl + k, y, Hi, Ho, align) : 0.f;
+        if (xfit && yfit) {                            // every scale the networks use: both inner axes walk register-held weights
+            for (int oz = zl; oz <= zh; ++oz) {
+                const float wz = tri_w(oz, z, Di, Do, align);
+                if (wz == 0.f) continue;
+                const T* plane = GY + ((((long long)b * Do + oz) * Ho + yl) * Wo + xl) * ldy + coff + cg * VN;
+#pragma unroll
+                for (int ky = 0; ky < MAXO; ++ky) {
+                    const float wzy = wz * wys[ky];
+                    if (wzy == 0.f) continue;
+                    const T* row = plane + (long long)ky * Wo * ldy;
 #pragma unroll
                     for (int k = 0; k < MAXO; ++k) {
                         const float w = wzy * wxs[k];
@@ -196,7 +224,16 @@ __global__ void trilinear_bwd_kernel(const T* __restrict__ GY, T* __restrict__ G
 #pragma unroll
                         for (int e = 0; e < VN; ++e) acc[e] += w * g.get(e);
                     }
-                } else {      // very large scale factors: evaluate in place
+                }
+            }
+        } else {                                       // very large scale factors: evaluate in place
+            for (int oz = zl; oz <= zh; ++oz) {
+                const float wz = tri_w(oz, z, Di, Do, align);
+                if (wz == 0.f) continue;
+                for (int oy = yl; oy <= yh; ++oy) {
+                    const float wzy = wz * tri_w(oy, y, Hi, Ho, align);
+                    if (wzy == 0.f) continue;
+                    const T* row = GY + ((((long long)b * Do + oz) * Ho + oy) * Wo + xl) * ldy + coff + cg * VN;
                     for (int ox = xl; ox <= xh; ++ox) {
                         const float w = wzy * tri_w(ox, x, Wi, Wo, align);
                         if (w == 0.f) continue;

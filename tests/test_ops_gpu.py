@@ -263,6 +263,23 @@ def test_golden_pool_trilinear():
     relclose(nc(yb)[:, :3], T(g["tri_up2.y"]), 1e-2, "tri bf16")
 
 
+@pytest.mark.parametrize("shape,out,align", [((2, 7, 6, 5), (14, 12, 10), False), ((1, 6, 6, 6), (12, 12, 12), True),
+                                             ((1, 5, 7, 3), (12, 9, 13), False), ((2, 4, 3, 5), (9, 11, 6), True),
+                                             ((1, 3, 4, 2), (14, 18, 9), True)])
+def test_trilinear_vs_torch(shape, out, align):
+    """Forward and gathered adjoint against torch's upsample_trilinear3d at ragged sizes, non-integer and > 4 scale factors (the
+    adjoint's candidate-output ranges and register-held per-axis weights, and the fall-back beyond 12 candidates per axis)."""
+    torch.manual_seed(5)
+    B, C = shape[0], 8
+    x = torch.randn(B, C, *shape[1:], requires_grad=True)
+    y = F.interpolate(x, size=out, mode="trilinear", align_corners=align)
+    r = torch.randn_like(y)
+    (gx,) = torch.autograd.grad(y, x, r)
+    xd = nd(x.detach())
+    close(nc(ops.trilinear_fwd(xd, out, align)), y, 1e-5, 1e-6)
+    close(nc(ops.trilinear_bwd(nd(r), xd.shape, align)), gx, 1e-4, 1e-5)
+
+
 def test_pointwise():
     x = torch.randn(2, 4, 5, 6, 16, device=DEV)
     scale = torch.rand(2 * 16, device=DEV)
