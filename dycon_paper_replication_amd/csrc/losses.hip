@@ -906,25 +906,22 @@ __global__ __launch_bounds__(256, 2) void fecl_rows128_kernel(const bf16* __rest
                     if (gj >= N) continue;
                     if (PASS == 1) {
                         if (gj != gi) a0 = fmaxf(a0, v * inv_tau);
-                    } else if (PASS == 2) {
-                        if (mk4[e] == mrow) a1 += 1.f;
-                        else a0 += fexp<true>(v * inv_tau - mj4[e]);
+                    } else if (PASS == 2) {                      // branch-free (a divergent if / else walks both paths anyway)
+                        const bool same = mk4[e] == mrow;
+                        const float ex = fexp<true>(v * inv_tau - mj4[e]);
+                        a1 += same ? 1.f : 0.f;
+                        a0 += same ? 0.f : ex;
                     } else if (!teacher_tile) {
-                        if (mk4[e] == mrow) {
-                            a1 += 1.f;
-                            if (gj != gi) {
-                                float a, rr, lgP, adphi;
-                                fast_pair(v * inv_tau - mj4[e], nrow, a, rr, lgP, adphi);
-                                if (focal) {
-                                    const float om = nrow * rr;
-                                    a0 += -lgP * om * om;             // phi
-                                    hrow -= adphi * rr * rr;          // dphi * (-a / d^2)
-                                } else {
-                                    a0 += -lgP;                       // phi = -log P, dphi * (-a / d^2) = 1 / d
-                                    hrow += rr;
-                                }
-                            }
-                        }
+                        const bool same = mk4[e] == mrow;
+                        a1 += same ? 1.f : 0.f;
+                        float a, rr, lgP, adphi;
+                        fast_pair(v * inv_tau - mj4[e], nrow, a, rr, lgP, adphi);
+                        const float om = nrow * rr;
+                        const float phi = focal ? -lgP * om * om : -lgP;            // phi(P); without focal: -log P
+                        const float dh = focal ? -adphi * rr * rr : rr;              // dphi * (-a / d^2); without focal: 1 / d
+                        const bool on = same && gj != gi;
+                        a0 += on ? phi : 0.f;
+                        hrow += on ? dh : 0.f;
                     } else {
                         if (vi && mk4[e] != mrow && v > thr) { cnum += -flog<true>(1.f - v + 1e-18f); ccnt += 1.f; }
                     }
@@ -958,6 +955,209 @@ __global__ __launch_bounds__(256, 2) void fecl_rows128_kernel(const bf16* __rest
             atomicAdd(&out[0], (double)bs);
             if (Tb) { atomicAdd(&out[1], (double)bn); atomicAdd(&out[2], (double)bc); }
         }
+    }
+}
+
+// ---- the gradient pass on the same 128-row blocks.
+// After the transposed Gram product a lane holds, for its row i, the pair weights W_ij of 16 columns per 32-column half tile:
+// registers 4 g + e <-> column 8 g + 4 half + e.  The gradient GEMM gf^T[d][i] += sum_j F_J^T[d][j] W^T[j][i] contracts over j in ANY
+// order, so k-step s of a half tile is DEFINED as the 16 columns {16 s + 8 g' + 4 half + e : g' in {0, 1}}: its B operand (W^T, 8 values
+// per lane: k-slot 4 g' + e of this lane's half) is exactly registers 4 (2 s + g') + e of the lane's own accumulator -- converted to bf16
+// and packed, no LDS round trip and no cross-lane traffic -- and its A operand (F_J^T: feature d = the lane's M index, the same 8
+// columns) is two transposed LDS reads (ds_read_b64_tr_b16: 4 consecutive rows j of the tile at 16 features per 16-lane group).
+// gf (32 rows x Dm per wave) stays in registers for the whole column sweep: 8 NQ accumulator registers; one wave per SIMD.
+template <int NQ>
+__global__ __launch_bounds__(256, 1) void fecl_rows128_grad_kernel(const bf16* __restrict__ F, const bf16* __restrict__ Tch,
+                                                                   const float* __restrict__ mask, int N, int Dm, float tau, int focal,
+                                                                   float thr, const float* __restrict__ ws, const double* __restrict__ out,
+                                                                   const float* __restrict__ coef, float lambda_cross,
+                                                                   float* __restrict__ GS, int Btot, int CS, int tiles_per_split) {
+    constexpr int NDT = NQ / 2;                                   // 32-feature blocks of the gradient
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    const int stride = Dm + F2_PAD, tile_elems = FT * stride;
+    unsigned short* Fj = reinterpret_cast<unsigned short*>(lds_raw);                       // [2][64][stride]
+    float* cst = reinterpret_cast<float*>(lds_raw + ((size_t)2 * tile_elems * 2 + 15) / 16 * 16);   // [2][{max, mask, n, kappa, H}][64]
+    const int b = blockIdx.y, cs = blockIdx.z, i0 = blockIdx.x * F2_ROWS;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, rl = lane & 31, half = lane >> 5;
+    const long long BN = (long long)Btot * N, rb = (long long)b * N;
+    const float* wm = ws;
+    const float* wn = ws + (long long)CS * BN;
+    const float* wh = ws + 3LL * CS * BN;
+    const float* wk = ws + 4LL * CS * BN;
+    auto ld_max = [&](const float* base, long long idx) { float v = base[idx]; for (int z = 1; z < CS; ++z) v = fmaxf(v, base[z * BN + idx]); return v; };
+    auto ld_sum = [&](const float* base, long long idx) { float v = base[idx]; for (int z = 1; z < CS; ++z) v += base[z * BN + idx]; return v; };
+    const unsigned short* Fb = reinterpret_cast<const unsigned short*>(F) + (long long)b * N * Dm;
+    const unsigned short* Tb = Tch ? reinterpret_cast<const unsigned short*>(Tch) + (long long)b * N * Dm : nullptr;
+    const float* mb = mask + rb;
+
+    const int gi = i0 + 32 * wave + rl;
+    const bool vi = gi < N;
+    uint4 bfrag[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        bfrag[q] = make_uint4(0, 0, 0, 0);
+        if (vi) bfrag[q] = *reinterpret_cast<const uint4*>(Fb + (long long)gi * Dm + 16 * q + 8 * half);
+    }
+    const float mrow = vi ? mb[gi] : -1.f;
+    float mi = 0.f, nrow = 0.f, krow = 0.f, hrow = 0.f;
+    if (vi) { mi = ld_max(wm, rb + gi); nrow = ld_sum(wn, rb + gi); krow = wk[rb + gi]; hrow = ld_sum(wh, rb + gi); }
+    const float inv_tau = 1.f / tau;
+    const float stud_scale = coef[0] / (float)BN * inv_tau;
+    const float cross_scale = Tb ? coef[0] * lambda_cross / ((float)out[2] + 1e-18f) : 0.f;
+    f32x16 gacc[NDT];
+#pragma unroll
+    for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) gacc[dt][e] = 0.f;
+
+    const int ppr = Dm >> 3, rstep = 256 / ppr, rr0 = threadIdx.x / ppr, k0 = (threadIdx.x - rr0 * ppr) << 3;
+    constexpr int NPF = 8;
+    uint4 pfr[NPF];
+    float pst[5] = {0.f, -2.f, 0.f, 0.f, 0.f};
+    const bool cross = Tb != nullptr;
+    const int j_beg = cs * tiles_per_split * FT, j_end = min(N, (cs + 1) * tiles_per_split * FT);
+    const int ntile = j_end > j_beg ? (j_end - j_beg + FT - 1) / FT : 0;
+    const int nst = cross ? 2 * ntile : ntile;
+    auto col0 = [&](int s_) { return j_beg + (cross ? s_ >> 1 : s_) * FT; };
+    auto prefetch = [&](int s_) {
+        const bool tt = cross && (s_ & 1);
+        const unsigned short* src = tt ? Tb : Fb;
+        const int row0 = col0(s_);
+#pragma unroll
+        for (int it = 0; it < NPF; ++it) {
+            const int rr = rr0 + it * rstep;
+            pfr[it] = make_uint4(0, 0, 0, 0);
+            if (rr < FT && row0 + rr < N) pfr[it] = *reinterpret_cast<const uint4*>(src + (long long)(row0 + rr) * Dm + k0);
+        }
+        if (threadIdx.x < FT) {
+            const int gc = row0 + threadIdx.x;
+            const bool vc = gc < N;
+            pst[1] = vc ? mb[gc] : -2.f;
+            if (!tt) {
+                pst[0] = vc ? ld_max(wm, rb + gc) : 0.f;
+                pst[2] = vc ? ld_sum(wn, rb + gc) : 0.f;
+                pst[3] = vc ? wk[rb + gc] : 0.f;
+                pst[4] = vc ? ld_sum(wh, rb + gc) : 0.f;
+            }
+        }
+    };
+    auto commit = [&](int buf) {
+        unsigned short* dst = Fj + buf * tile_elems;
+#pragma unroll
+        for (int it = 0; it < NPF; ++it) {
+            const int rr = rr0 + it * rstep;
+            if (rr < FT) *reinterpret_cast<uint4*>(dst + rr * stride + k0) = pfr[it];
+        }
+        if (threadIdx.x < FT) {
+#pragma unroll
+            for (int k = 0; k < 5; ++k) cst[(buf * 5 + k) * FT + threadIdx.x] = pst[k];
+        }
+    };
+
+    if (nst > 0) { prefetch(0); commit(0); }
+    if (nst > 1) prefetch(1);
+    __syncthreads();
+    for (int s_ = 0; s_ < nst; ++s_) {
+        const int buf = s_ & 1, j0 = col0(s_);
+        const unsigned short* tile = Fj + buf * tile_elems;
+        const unsigned short* At = tile + rl * stride + 8 * half;
+        f32x16 acc[2];
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[jt][e] = 0.f;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+#pragma unroll
+            for (int jt = 0; jt < 2; ++jt) {
+                const bf16x8_t a = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(At + jt * 32 * stride + 16 * q));
+                acc[jt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, __builtin_bit_cast(bf16x8_t, bfrag[q]), acc[jt], 0, 0, 0);
+            }
+        }
+        // pair weights, in place: acc[jt][4 g + e] <- W(i, column jt*32 + 8 g + 4 half + e)
+        const float* cb = cst + buf * 5 * FT;
+        const bool teacher_tile = cross && (s_ & 1);
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int jl = jt * 32 + 8 * g + 4 * half;
+                const float4 k4 = *reinterpret_cast<const float4*>(cb + FT + jl);
+                const float mk4[4] = {k4.x, k4.y, k4.z, k4.w};
+                if (teacher_tile) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float sx = acc[jt][4 * g + e];
+                        const bool hard = vi && j0 + jl + e < N && mk4[e] != mrow && sx > thr;
+                        acc[jt][4 * g + e] = hard ? cross_scale * __builtin_amdgcn_rcpf(1.f - sx + 1e-18f) : 0.f;
+                    }
+                } else {
+                    const float4 m4 = *reinterpret_cast<const float4*>(cb + jl);
+                    const float4 n4 = *reinterpret_cast<const float4*>(cb + 2 * FT + jl);
+                    const float4 q4 = *reinterpret_cast<const float4*>(cb + 3 * FT + jl);
+                    const float4 h4 = *reinterpret_cast<const float4*>(cb + 4 * FT + jl);
+                    const float mj4[4] = {m4.x, m4.y, m4.z, m4.w}, nj4[4] = {n4.x, n4.y, n4.z, n4.w};
+                    const float kj4[4] = {q4.x, q4.y, q4.z, q4.w}, hj4[4] = {h4.x, h4.y, h4.z, h4.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        // branch-free: both classes' terms are evaluated and one is selected.  The two directions share their
+                        // exponentials with the other-class term; a divergent if / else made every lane walk both paths anyway
+                        // (82 % of the pairs are same-class at the reference's 10 % foreground) with 3 exps per path and ~4 exec-mask
+                        // branch sequences per pair.  All operands are finite for masked-out pairs too (zero rows / columns).
+                        const int gj = j0 + jl + e;
+                        const float l = acc[jt][4 * g + e] * inv_tau;
+                        const float x1 = l - mj4[e], x2 = l - mi;
+                        const float e1 = fexp<true>(x1), e2 = fexp<true>(x2);
+                        const float r1 = __builtin_amdgcn_rcpf(e1 + nrow), r2 = __builtin_amdgcn_rcpf(e2 + nj4[e]);
+                        float same;
+                        if (focal) {                             // (uniform)  kappa n r^2 * a dphi,  a dphi = n r (2 a log P - n)
+                            const float lg1 = x1 + flog<true>(r1), lg2 = x2 + flog<true>(r2);      // log P = x - log d = x + log r
+                            const float t1 = nrow * r1, t2 = nj4[e] * r2;
+                            same = krow * t1 * t1 * r1 * (2.f * e1 * lg1 - nrow) + kj4[e] * t2 * t2 * r2 * (2.f * e2 * lg2 - nj4[e]);
+                        } else {
+                            same = -(krow * nrow * r1 + kj4[e] * nj4[e] * r2);              // dphi = -1 / P
+                        }
+                        const float diff = e1 * hrow + e2 * hj4[e];
+                        const float tv = mk4[e] == mrow ? same : diff;
+                        acc[jt][4 * g + e] = (vi && gj < N && gj != gi) ? tv * stud_scale : 0.f;
+                    }
+                }
+            }
+        // gradient GEMM: gacc[dt] (M = 32 features, N = the wave's 32 rows) += F_J^T (A, transposed LDS reads) x W^T (B, from acc)
+        const unsigned short* Arow = tile + (4 * half + ((lane & 15) >> 2)) * stride + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+            for (int sk = 0; sk < 2; ++sk) {
+                unsigned wb[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {                 // k-slot 4 g' + e <- register 4 (2 sk + g') + e
+                    const int r0 = 8 * sk + 2 * u;
+                    wb[u] = (unsigned)f32_to_bf16_bits(acc[jt][r0]) | ((unsigned)f32_to_bf16_bits(acc[jt][r0 + 1]) << 16);
+                }
+                const bf16x8_t wfrag = __builtin_bit_cast(bf16x8_t, make_uint4(wb[0], wb[1], wb[2], wb[3]));
+                const unsigned short* a0 = Arow + (jt * 32 + 16 * sk) * stride;
+#pragma unroll
+                for (int dt = 0; dt < NDT; ++dt) {
+                    const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr_t)(a0 + 32 * dt));
+                    const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr_t)(a0 + 32 * dt + 8 * stride));
+                    const s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    gacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, v), wfrag, gacc[dt], 0, 0, 0);
+                }
+            }
+        if (s_ + 1 < nst) commit(buf ^ 1);
+        if (s_ + 2 < nst) prefetch(s_ + 2);
+        __syncthreads();
+    }
+    // gacc[dt][4 g + e] = gf[row gi][feature 32 dt + 8 g + 4 half + e]
+    if (vi) {
+        float* gb = GS + (((long long)cs * Btot + b) * N + gi) * Dm;
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                *reinterpret_cast<float4*>(gb + 32 * dt + 8 * g + 4 * half) =
+                    make_float4(gacc[dt][4 * g], gacc[dt][4 * g + 1], gacc[dt][4 * g + 2], gacc[dt][4 * g + 3]);
     }
 }
 
@@ -1146,6 +1346,30 @@ static int fecl_rows128_launch(const void* feat, const void* teacher, const floa
     return fecl_rows128_launch_nq<PASS, 4>(feat, teacher, mask, gamb, B, N, Dm, tau, focal, thr, ws, out, stream);
 }
 
+template <int NQ>
+static int fecl_rows128_grad_launch_nq(const void* feat, const void* teacher, const float* mask, int B, int N, int Dm, float tau, int focal,
+                                       float thr, float* ws, const double* out, const float* coef, float lambda_cross, dycon_stream_t stream) {
+    const size_t lds = ((size_t)2 * FT * (Dm + F2_PAD) * 2 + 15) / 16 * 16 + 2 * 5 * FT * sizeof(float);
+    if (hipFuncSetAttribute((const void*)fecl_rows128_grad_kernel<NQ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+        dycon_set_error("fecl: cannot reserve %zu bytes of LDS", lds);
+        return DYCON_ERR_LAUNCH;
+    }
+    int CS, tps;
+    fecl_split(B, N, CS, tps);
+    float* gslab = ws + (size_t)(4 * CS + 1) * B * N;
+    dim3 grid(cdiv(N, F2_ROWS), B, CS);
+    fecl_rows128_grad_kernel<NQ><<<grid, 256, lds, stream>>>((const bf16*)feat, (const bf16*)teacher, mask, N, Dm, tau, focal, thr, ws, out, coef,
+                                                             lambda_cross, gslab, B, CS, tps);
+    DYCON_LAUNCH_CHECK();
+    return DYCON_OK;
+}
+static int fecl_rows128_grad_launch(const void* feat, const void* teacher, const float* mask, int B, int N, int Dm, float tau, int focal,
+                                    float thr, float* ws, const double* out, const float* coef, float lambda_cross, dycon_stream_t stream) {
+    if (Dm == 256) return fecl_rows128_grad_launch_nq<16>(feat, teacher, mask, B, N, Dm, tau, focal, thr, ws, out, coef, lambda_cross, stream);
+    if (Dm == 128) return fecl_rows128_grad_launch_nq<8>(feat, teacher, mask, B, N, Dm, tau, focal, thr, ws, out, coef, lambda_cross, stream);
+    return fecl_rows128_grad_launch_nq<4>(feat, teacher, mask, B, N, Dm, tau, focal, thr, ws, out, coef, lambda_cross, stream);
+}
+
 static int fecl_check(const char* who, const void* feat, const float* mask, int B, int N, int Dm, float tau, size_t ws_bytes) {
     DYCON_REQUIRE(feat && mask && B > 0 && N > 0 && Dm > 0 && tau > 0.f, "%s: bad arguments", who);
     DYCON_REQUIRE(Dm <= 256, "%s: feature dim %d > 256 not supported", who, Dm);
@@ -1195,9 +1419,13 @@ extern "C" int dycon_fecl_bwd(const void* feat, const void* teacher, const float
     DYCON_REQUIRE(out && coef && g_feat && workspace, "fecl_bwd: null pointer");
     const int focal = use_focal && !gambling;
     int e = DYCON_OK;
+    static const bool grad128 = getenv("DYCON_FECL_GRAD128") == nullptr || atoi(getenv("DYCON_FECL_GRAD128")) != 0;
     DYCON_DISPATCH(dtype, {
-        e = fecl_launch<T, 4>(feat, teacher, mask, gambling, B, N, Dm, temperature, gamma, focal, cross_thresh, workspace,
-                              const_cast<double*>(out), coef, lambda_cross, stream);
+        if (grad128 && fecl_rows128_ok(dtype, B, N, Dm, gamma, focal))
+            e = fecl_rows128_grad_launch(feat, teacher, mask, B, N, Dm, temperature, focal, cross_thresh, workspace, out, coef, lambda_cross, stream);
+        else
+            e = fecl_launch<T, 4>(feat, teacher, mask, gambling, B, N, Dm, temperature, gamma, focal, cross_thresh, workspace,
+                                  const_cast<double*>(out), coef, lambda_cross, stream);
         if (!e) {
             int CS, tps;
             fecl_split(B, N, CS, tps);
