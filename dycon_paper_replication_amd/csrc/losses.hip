@@ -1271,10 +1271,14 @@ extern "C" int dycon_mask_pool(const void* labels, int label_bytes, float* mask,
     return DYCON_OK;
 }
 
-// column splits: enough workgroups to occupy the chip twice over (LDS allows 2 per CU)
-static void fecl_split(int B, int N, int& CS, int& tps) {
+// column splits: enough workgroups to occupy the chip twice over (LDS allows 2 per CU).  r128 (the 128-row kernels; their gradient
+// pass holds ONE workgroup per CU): few row blocks (N = 1728: 14 per sample) -> as many splits as keep the grid within one round
+// of 256, otherwise the split count nearest to 512 workgroups.
+static void fecl_split(int B, int N, bool r128, int& CS, int& tps) {
     const int nct = (N + FT - 1) / FT;
-    long long want = (512 + (long long)nct * B - 1) / ((long long)nct * B);
+    const long long blocks = (long long)((N + (r128 ? 128 : FT) - 1) / (r128 ? 128 : FT)) * B;
+    long long want = (512 + blocks - 1) / blocks;
+    if (r128) want = blocks <= 128 ? 256 / blocks : (512 + blocks / 2) / blocks;
     if (want > 8) want = 8;
     if (want > nct) want = nct;
     if (want < 1) want = 1;
@@ -1283,8 +1287,10 @@ static void fecl_split(int B, int N, int& CS, int& tps) {
 }
 
 extern "C" size_t dycon_fecl_workspace(int B, int N, int Dm) {
-    int CS, tps;
-    fecl_split(B, N, CS, tps);
+    int CS, CS2, tps;
+    fecl_split(B, N, false, CS, tps);
+    fecl_split(B, N, true, CS2, tps);
+    if (CS2 > CS) CS = CS2;                      // whichever kernel family the dtype / size selects later
     return ((size_t)(4 * CS + 1) * B * N + (size_t)CS * B * N * Dm) * sizeof(float);
 }
 
@@ -1307,7 +1313,7 @@ static int fecl_launch(const void* feat, const void* teacher, const float* mask,
         return DYCON_ERR_LAUNCH;
     }
     int CS, tps;
-    fecl_split(B, N, CS, tps);
+    fecl_split(B, N, false, CS, tps);
     float* gslab = ws + (size_t)(4 * CS + 1) * B * N;
     dim3 grid(cdiv(N, FT), B, CS);
     fecl_kernel<T, PASS><<<grid, 256, lds, stream>>>((const T*)feat, (const T*)teacher, mask, gamb, N, Dm, tau, gamma, focal, thr, ws,
@@ -1317,9 +1323,10 @@ static int fecl_launch(const void* feat, const void* teacher, const float* mask,
 }
 
 // passes 1-3 on the 128-row kernel: bf16, a feature dim whose rows split into equal 16-byte columns per thread, the focal weight the
-// reference runs (gamma = 2) or none, and N large enough that one round of 128-row blocks fills the chip
+// reference runs (gamma = 2) or none, and N >= 1024 (8 row blocks per sample; the headline N = 1728 runs 0.27 -> 0.25 ms alone
+// and the step 4.72 -> 4.64 ms with them, profiles/r03_fecl_n15680.txt)
 static bool fecl_rows128_ok(int dtype, int B, int N, int Dm, float gamma, int focal) {
-    static const long long min_n = [] { const char* v = getenv("DYCON_FECL_ROWS128_MIN_N"); return v && *v ? atoll(v) : 8192LL; }();
+    static const long long min_n = [] { const char* v = getenv("DYCON_FECL_ROWS128_MIN_N"); return v && *v ? atoll(v) : 1024LL; }();
     return dtype == DYCON_BF16 && (Dm == 64 || Dm == 128 || Dm == 256) && (!focal || gamma == 2.f) && N >= min_n;
 }
 template <int PASS, int NQ>
@@ -1331,7 +1338,7 @@ static int fecl_rows128_launch_nq(const void* feat, const void* teacher, const f
         return DYCON_ERR_LAUNCH;
     }
     int CS, tps;
-    fecl_split(B, N, CS, tps);
+    fecl_split(B, N, true, CS, tps);
     dim3 grid(cdiv(N, F2_ROWS), B, CS);
     fecl_rows128_kernel<PASS, NQ><<<grid, 256, lds, stream>>>((const bf16*)feat, (const bf16*)teacher, mask, gamb, N, Dm, tau, focal, thr, ws,
                                                               out, B, CS, tps);
@@ -1355,7 +1362,7 @@ static int fecl_rows128_grad_launch_nq(const void* feat, const void* teacher, co
         return DYCON_ERR_LAUNCH;
     }
     int CS, tps;
-    fecl_split(B, N, CS, tps);
+    fecl_split(B, N, true, CS, tps);
     float* gslab = ws + (size_t)(4 * CS + 1) * B * N;
     dim3 grid(cdiv(N, F2_ROWS), B, CS);
     fecl_rows128_grad_kernel<NQ><<<grid, 256, lds, stream>>>((const bf16*)feat, (const bf16*)teacher, mask, N, Dm, tau, focal, thr, ws, out, coef,
@@ -1419,16 +1426,16 @@ extern "C" int dycon_fecl_bwd(const void* feat, const void* teacher, const float
     DYCON_REQUIRE(out && coef && g_feat && workspace, "fecl_bwd: null pointer");
     const int focal = use_focal && !gambling;
     int e = DYCON_OK;
-    static const bool grad128 = getenv("DYCON_FECL_GRAD128") == nullptr || atoi(getenv("DYCON_FECL_GRAD128")) != 0;
+    const bool r128 = fecl_rows128_ok(dtype, B, N, Dm, gamma, focal);
     DYCON_DISPATCH(dtype, {
-        if (grad128 && fecl_rows128_ok(dtype, B, N, Dm, gamma, focal))
+        if (r128)
             e = fecl_rows128_grad_launch(feat, teacher, mask, B, N, Dm, temperature, focal, cross_thresh, workspace, out, coef, lambda_cross, stream);
         else
             e = fecl_launch<T, 4>(feat, teacher, mask, gambling, B, N, Dm, temperature, gamma, focal, cross_thresh, workspace,
                                   const_cast<double*>(out), coef, lambda_cross, stream);
         if (!e) {
             int CS, tps;
-            fecl_split(B, N, CS, tps);
+            fecl_split(B, N, r128, CS, tps);
             const long long n = (long long)B * N * Dm;
             fecl_combine_kernel<T><<<lgrid(n), 256, 0, stream>>>(workspace + (size_t)(4 * CS + 1) * B * N, CS, n, (T*)g_feat);
         }

@@ -477,9 +477,11 @@ def test_fecl_isles_size_vs_rowblock_oracle():
 
 @pytest.mark.parametrize("Dm,focal,use_t,use_g", [(256, True, True, False), (64, False, True, True), (128, True, False, False)])
 def test_fecl_rows128_kernel_vs_oracle(Dm, focal, use_t, use_g):
-    """N >= 8192 in bf16 storage takes passes 1-3 on fecl_rows128_kernel (128-row blocks, 32x32x16 MFMA, row fragments in registers)
-    and the gradient pass on fecl_kernel<bf16, 4> reading what they left: loss and gradient against the fp32 oracle on the rounded
-    inputs, at an N that is a multiple of neither 64 nor 128 (ragged last row block, column tile and column split)."""
+    """N >= 1024 in bf16 storage (Dm 64 / 128 / 256, focal gamma 2 or no focal) runs on the 128-row kernels (fecl_rows128_kernel for
+    passes 1-3, fecl_rows128_grad_kernel for the gradient: 32x32x16 MFMA, row fragments in registers): loss and gradient against the
+    fp32 oracle on the rounded inputs, at an N that is a multiple of neither 64 nor 128 (ragged last row block, column tile and
+    column split), with two column splits.  (test_fecl_bf16_and_full_size covers the headline N = 1728 on the same kernels;
+    the fp32-storage cases and N < 1024 stay on fecl_kernel.)"""
     torch.manual_seed(11)
     B, N = 2, 8200
     f = F.normalize(torch.randn(B, N, Dm), dim=-1).bfloat16()
