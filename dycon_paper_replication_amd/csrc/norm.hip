@@ -9,12 +9,17 @@
 // partials live in registers); the grid-wide reduction is two-stage and deterministic:
 // per-chunk partials -> tiny finalize kernel (double accumulation).
 #include "common.h"
+#include <type_traits>
 
 struct NormPlan { int chunks; long long rows_per_chunk; };
 static NormPlan norm_plan(long long V) {
     NormPlan p;
-    long long rpc = (V + 511) / 512;     // <= 512 chunks per sample ...
-    if (rpc < 64) rpc = 64;              // ... of >= 64 rows (small levels: many short chunks, not few long serial ones)
+    static const long long maxc = [] { const char* v = getenv("DYCON_NORM_CHUNKS"); return v && *v ? atoll(v) : 256LL; }();
+    long long rpc = (V + maxc - 1) / maxc;     // <= 256 chunks per sample ...
+    static const long long minr = [] { const char* v = getenv("DYCON_NORM_MIN_ROWS"); return v && *v ? atoll(v) : 128LL; }();
+    if (rpc < minr) rpc = minr;          // ... of >= 128 rows.  (Round 3: 512 chunks of >= 64 rows -> 256 of >= 128: the step 4.54 -> 4.47 ms over two
+                                         // pairs, profiles/r03_norm_chunk_plan.txt -- per-workgroup fixed cost (launch ramp, the LDS tree, the partial
+                                         // stores and the finalize that sums them) against the length of the serial row loop; 128 / 1024 chunks are slower.)
     p.rows_per_chunk = rpc;
     p.chunks = (int)((V + rpc - 1) / rpc);
     return p;
@@ -33,16 +38,20 @@ __global__ __launch_bounds__(256) void norm_partial_kernel(const T* __restrict__
                                                            int relu, int from_y, const float* __restrict__ chan_scale,
                                                            double* __restrict__ acc = nullptr, int nslots = 1) {
     constexpr int VN = Vec16<T>::N;
-    __shared__ float sm[2][256][VN + 1];
+    // fp32 storage (the 1e-4 parity mode): the per-thread sums are kept in double -- that mode's budget against the fp64 twin of the
+    // reference (twice the reference's own fp32 error on the logits after an optimiser step) leaves no room for an fp32 chain whose
+    // length depends on the chunk plan.  bf16 storage: fp32 (the stored values carry 2^-9 noise each).
+    typedef typename std::conditional<sizeof(T) == 4, double, float>::type A;
+    __shared__ A sm[2][256][VN + 1];
     const int n = blockIdx.y, chunk = blockIdx.x;
     const int ngrp = C / VN;            // 16-byte groups per row
     const int rpi = 256 / ngrp;         // rows per iteration (0 if C/VN > 256: rejected on the host)
     const int cg = threadIdx.x % ngrp, rr = threadIdx.x / ngrp;
     const long long v0 = chunk * rows_per_chunk, v1 = min(V, v0 + rows_per_chunk);
     const int cpg = C / G;
-    float a0[VN], a1[VN];
+    A a0[VN], a1[VN];
 #pragma unroll
-    for (int k = 0; k < VN; ++k) a0[k] = a1[k] = 0.f;
+    for (int k = 0; k < VN; ++k) a0[k] = a1[k] = 0;
     float mean[VN], rstd[VN], gm[VN], bt[VN], cs[VN];
     if (MODE == 1) {
 #pragma unroll
@@ -64,7 +73,7 @@ __global__ __launch_bounds__(256) void norm_partial_kernel(const T* __restrict__
             if (MODE == 0) {
 #pragma unroll
                 for (int k = 0; k < VN; ++k) {
-                    const float x = s.get(k);
+                    const A x = s.get(k);
                     a0[k] += x;
                     a1[k] += x * x;
                 }
@@ -81,8 +90,8 @@ __global__ __launch_bounds__(256) void norm_partial_kernel(const T* __restrict__
                         xh = (s.get(k) - mean[k]) * rstd[k];
                         if (relu && !(gm[k] * xh + bt[k] > 0.f)) g = 0.f;
                     }
-                    a0[k] += g;
-                    a1[k] += g * xh;
+                    a0[k] += (A)g;
+                    a1[k] += (A)g * (A)xh;
                 }
             }
         }
@@ -93,8 +102,11 @@ __global__ __launch_bounds__(256) void norm_partial_kernel(const T* __restrict__
     // thread (cg, k) pairs: C outputs x 2
     for (int o = threadIdx.x; o < C; o += 256) {
         const int og = o / VN, ok = o % VN;
-        float s0 = 0.f, s1 = 0.f;
-        for (int q = 0; q < rpi; ++q) { s0 += sm[0][q * ngrp + og][ok]; s1 += sm[1][q * ngrp + og][ok]; }
+        // the workgroup's per-thread sums are combined in double: with 256 chunks per sample (round 3; 512 before) a chunk's sum is a
+        // longer fp32 chain, and the fp32 parity mode's logits budget (twice the reference's own fp32 error) is tight at step 1
+        double s0d = 0.0, s1d = 0.0;
+        for (int q = 0; q < rpi; ++q) { s0d += (double)sm[0][q * ngrp + og][ok]; s1d += (double)sm[1][q * ngrp + og][ok]; }
+        const float s0 = (float)s0d, s1 = (float)s1d;
         if (acc) {     // chunk -> one of nslots copies: <= chunks/nslots adds per address (same-address atomics serialise at the memory side)
             double* a = acc + (((long long)n * nslots + chunk % nslots) * C + o) * 2;
             atomicAdd(a, (double)s0);
@@ -721,8 +733,10 @@ extern "C" int dycon_norm_fwd(const void* x, void* y, int dtype, int Nb, long lo
 }
 
 static int apply_grid(long long V, int C, int VN) {
-    long long blocks = (V * C / VN + 256 * 4 - 1) / (256 * 4);
-    if (blocks > 2048) blocks = 2048;
+    static const long long vpt = [] { const char* v = getenv("DYCON_NORM_APPLY_VPT"); return v && *v ? atoll(v) : 4LL; }();
+    static const long long cap = [] { const char* v = getenv("DYCON_NORM_APPLY_CAP"); return v && *v ? atoll(v) : 2048LL; }();
+    long long blocks = (V * C / VN + 256 * vpt - 1) / (256 * vpt);
+    if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
     return (int)blocks;
 }
