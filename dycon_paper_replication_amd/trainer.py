@@ -419,6 +419,18 @@ class DyconTrainer:
             t_drop = DropoutSpec("philox", seed=seed, offset=(2 * it + 1) << 42) if c.teacher_mode == "train" else DropoutSpec("off")
 
         self._mark("step_begin")
+        # coef = d total / d (ce, dice_fg, dice_mc, cons, uncl | fecl): host-known, so it is written at the head of the step -- the
+        # feature branch's backward (FeCL gradient, embeddings, projection head) then depends on nothing but its own forward and MAY
+        # start as soon as that is done, beside the student's decoder, instead of behind the scalar end of the loss on the main stream
+        # (DYCON_FEAT_BWD_EARLY=1).  Measured: 15.07 -> 15.00 ms at 112 x 112 x 80, where that branch is the step's critical path, but
+        # 4.45 -> 4.48 ms on the headline step (it then shares the CUs with the student's HBM-bound top level): off by default.
+        # Means over equal shards (CE, cons, UnCL, FeCL student part) become global through the 1/world arena average;
+        # the two global-ratio terms are differentiated w.r.t. LOCAL voxels and must be SUMMED over ranks -> x world.
+        glob = self.ddp and c.global_batch_losses
+        gw = self.world if glob else 1
+        dice_kind = 0 if c.dice_variant == "fg" else 1
+        ops.set_scalars(self.coef, [c.l_weight, c.l_weight * (1 - dice_kind) * gw, c.l_weight * dice_kind * gw, cw,
+                                    c.u_weight, c.u_weight])
         ops.rec(lambda: self.sumsq.zero_())          # (its first use is mid-backward at the earliest)
         if self.acc_arena is not None:
             arena = self.acc_arena
@@ -497,7 +509,6 @@ class DyconTrainer:
         self._mark("student_fwd_end")
         # ---- losses (:308-357)
         world = self.world
-        glob = self.ddp and c.global_batch_losses
         # the step's 16 + 4 loss accumulators live in ONE buffer: a data-parallel run exchanges them with one all-reduce
         sums, fo = self.acc20[:16], self.acc20[16:]
         ops.seg_losses_fwd(s_logits, t_logits, label, LB, beta, fast=self._fast_math, out=sums)
@@ -527,14 +538,11 @@ class DyconTrainer:
             ops.fork(feat, main)       # the scalar loss (and the DDP exchange below) needs the FeCL sums
             for t in (t_feat, mask):
                 t.record_stream(main)
-        gw = 1
         if glob:
             # Dice is a ratio of batch-GLOBAL sums (losses.py:11-14) and the FeCL cross branch a global sum over a
             # global count (dycon_losses.py:229): exchange the 16 + 4 accumulators (one collective), then finalise on every rank
             acc20 = self.acc20
             ops.rec(lambda: torch.distributed.all_reduce(acc20, group=self.pg))
-            gw = world
-        dice_kind = 0 if c.dice_variant == "fg" else 1
         cons_kind = 0 if c.consistency_type == "mse" else 1
         # the scalar end of the loss forward (:355-362) in one launch: voxel-loss ratios, FeCL finalize, weighted total, NaN/Inf flag
         out = ops.step_losses(sums, fo, B * gw, LB * gw, V, beta, B * gw * s_emb.shape[1], 1.0, teacher_emb is not None,
@@ -542,15 +550,11 @@ class DyconTrainer:
         if c.strict_nan_check:
             ops.rec(lambda: (self.flag_host.copy_(self.flag, non_blocking=True), self.flag_evt.record(main)))
 
-        # ---- backward (:364-365).  coef = d total / d (ce, dice_fg, dice_mc, cons, uncl | fecl).
-        # Means over equal shards (CE, cons, UnCL, FeCL student part) become global through the 1/world arena average;
-        # the two global-ratio terms are differentiated w.r.t. LOCAL voxels and must be SUMMED over ranks -> x world.
-        ops.set_scalars(self.coef, [c.l_weight, c.l_weight * (1 - dice_kind) * gw, c.l_weight * dice_kind * gw, cw,
-                                    c.u_weight, c.u_weight])
+        # ---- backward (:364-365); coef was written at the head of the step
         self._mark("loss_end")
         g_logits = ops.seg_losses_bwd(s_logits, t_logits, label, LB, beta, sums, self.coef, cons_kind, fast=self._fast_math)
-        if self.feat is not None:
-            ops.fork(main, feat)       # coef (and, with DDP, the all-reduced FeCL sums)
+        if self.feat is not None and (glob or os.environ.get("DYCON_FEAT_BWD_EARLY", "0") != "1"):
+            ops.fork(main, feat)       # DDP: the all-reduced FeCL sums (cross-branch count) are exchanged on main
         with fctx():
             if "feat_bwd" in ABLATE:     # tools/ablate.py (timing only): the feature branch's loss backward switched off
                 g_feat = torch.zeros_like(s_feat)
